@@ -1,0 +1,82 @@
+"""ctypes binding of libdeepmod_hip.so (include/deepmod_hip.h).  No fallbacks: if the HIP
+library is missing or no gfx950 device is usable, every entry point raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libdeepmod_hip.so")
+
+DM_OPT_PROFILE = 1
+DM_OPT_PRECISION = 2
+DM_PREC_F32 = 0
+DM_PREC_F16X3 = 1
+DM_WEIGHT_FLOATS = 408402
+
+_c = ctypes
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+
+# (name, restype, argtypes) — mirrors include/deepmod_hip.h one to one
+SIGNATURES = [
+    ("dm_last_error", _c.c_char_p, []),
+    ("dm_version", _c.c_char_p, []),
+    ("dm_device_count", _c.c_int, []),
+    ("dm_model_create", _vp, [_c.c_int, _vp, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    ("dm_model_destroy", None, [_vp]),
+    ("dm_model_set_option", _c.c_int, [_vp, _c.c_int, _i64]),
+    ("dm_predict_windows", _c.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    ("dm_predict_read", _c.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    ("dm_model_sync", _c.c_int, [_vp]),
+    ("dm_profile_reset", _c.c_int, [_vp]),
+    ("dm_profile_get", _c.c_int, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_i64), _c.POINTER(_i64)]),
+    ("dm_device_alloc", _vp, [_c.c_int, _c.c_size_t]),
+    ("dm_device_free", _c.c_int, [_c.c_int, _vp]),
+    ("dm_memcpy_h2d", _c.c_int, [_c.c_int, _vp, _vp, _c.c_size_t]),
+    ("dm_memcpy_d2h", _c.c_int, [_c.c_int, _vp, _vp, _c.c_size_t]),
+    ("dm_summary_create", _vp, [_c.c_int, _i64]),
+    ("dm_summary_destroy", None, [_vp]),
+    ("dm_summary_length", _i64, [_vp]),
+    ("dm_summary_add", _c.c_int, [_vp, _vp, _vp, _i64]),
+    ("dm_summary_add_classified", _c.c_int, [_vp, _vp, _vp, _vp, _i64]),
+    ("dm_summary_sync", _c.c_int, [_vp]),
+    ("dm_rccl_unique_id", _c.c_int, [_vp]),
+    ("dm_summary_reduce_rccl", _c.c_int, [_vp, _vp, _c.c_int, _c.c_int]),
+    ("dm_summary_fetch", _c.c_int, [_vp, _vp, _vp, _vp]),
+    ("dm_summary_device_ptr", _vp, [_vp]),
+]
+
+
+class DeepModHipError(RuntimeError):
+    pass
+
+
+_LIB: Optional[ctypes.CDLL] = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the in-tree HIP library (built by __graft_entry__.build()).  Raises if absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise DeepModHipError(
+                "%s not found - build it first (python -c 'import __graft_entry__ as g; g.build()'); "
+                "there is no CPU fallback" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, restype, argtypes in SIGNATURES:
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = lib
+    return _LIB
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise DeepModHipError("deepmod_hip error %d: %s" % (rc, load().dm_last_error().decode("utf-8", "replace")))
+
+
+def last_error() -> str:
+    return load().dm_last_error().decode("utf-8", "replace")

@@ -1,0 +1,709 @@
+// deepmod_hip.hip — libdeepmod_hip.so: C ABI (include/deepmod_hip.h) + host runtime for gfx950.
+// Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see __graft_entry__.build()).
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/deepmod_hip.h"
+#include "lstm_f32.hip.inc"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(DM_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // clear sticky "invalid value" for plain host memory
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing (host): canonical flat blob -> MFMA consumption order
+// ---------------------------------------------------------------------------------------------
+// column of the TF kernel ([.., 400] = i|j|f|o blocks of 100) held by N-tile t, tile column c
+inline int gate_col(int t, int c) {
+    if (t < 24) return (t & 3) * 100 + 16 * (t >> 2) + c;
+    return (c >> 2) * 100 + 96 + (c & 3);
+}
+
+struct Packed {
+    std::vector<float> w, b, h;
+    float bout[2];
+};
+
+Packed pack_weights(const float* flat) {
+    using namespace lstm32;
+    Packed P;
+    P.w.assign(size_t(2) * KS_DIR * KSTEP_F, 0.0f);
+    P.b.assign(size_t(6) * 400, 0.0f);
+    P.h.assign(size_t(2) * 25 * 64, 0.0f);
+    const float* p = flat;
+    for (int d = 0; d < 2; ++d) {
+        int ks_base = 0;
+        for (int l = 0; l < 3; ++l) {
+            const int kin = l == 0 ? NFEAT : HID;
+            const int ksin = l == 0 ? 2 : 25;
+            const float* kern = p;
+            p += size_t(kin + HID) * 400;
+            const float* bias = p;
+            p += 400;
+            for (int ks = 0; ks < ksin + 25; ++ks) {
+                float* dst = P.w.data() + size_t(d * KS_DIR + ks_base + ks) * KSTEP_F;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int sub = lane >> 4, c = lane & 15;
+                    int krow;  // row of the TF kernel feeding this (k-step, sub-k); -1 = zero padding
+                    if (ks < ksin) {
+                        const int k = 4 * ks + sub;
+                        krow = k < kin ? k : -1;
+                    } else {
+                        krow = kin + 4 * (ks - ksin) + sub;
+                    }
+                    for (int t = 0; t < NT; ++t) {
+                        const float v = krow < 0 ? 0.0f : kern[size_t(krow) * 400 + gate_col(t, c)];
+                        if (t < 24) dst[((t >> 2) * 64 + lane) * 4 + (t & 3)] = v;
+                        else dst[6 * 256 + lane] = v;
+                    }
+                }
+            }
+            float* bd = P.b.data() + size_t(d * 3 + l) * 400;
+            for (int t = 0; t < NT; ++t)
+                for (int c = 0; c < 16; ++c) {
+                    const int gc = gate_col(t, c);
+                    bd[t * 16 + c] = bias[gc] + ((gc >= 200 && gc < 300) ? 1.0f : 0.0f);  // forget_bias=1.0
+                }
+            ks_base += ksin + 25;
+        }
+    }
+    const float* wout = p;  // [200][2]
+    const float* bo = p + 400;
+    for (int d = 0; d < 2; ++d)
+        for (int kh = 0; kh < 25; ++kh)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int c = lane & 15, sub = lane >> 4;
+                P.h[(size_t(d) * 25 + kh) * 64 + lane] = c < 2 ? wout[(d * HID + 4 * kh + sub) * 2 + c] : 0.0f;
+            }
+    P.bout[0] = bo[0];
+    P.bout[1] = bo[1];
+    return P;
+}
+
+// ---------------------------------------------------------------------------------------------
+// summary kernel: dense int32 counters, one atomic per qualifying base
+// ---------------------------------------------------------------------------------------------
+__global__ void summary_add_kernel(int* __restrict__ touch, int* __restrict__ cov, int* __restrict__ mod,
+                                   const long long length, const long long* __restrict__ pos,
+                                   const unsigned char* __restrict__ flags,
+                                   const unsigned char* __restrict__ cls, const long long n,
+                                   int* __restrict__ oob) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        unsigned f = flags[i];
+        if (cls) f = (f & 3u) | (cls[i] == 1 ? 4u : 0u);
+        if (!(f & 1u)) continue;
+        const long long q = pos[i];
+        if (q < 0 || q >= length) {
+            atomicAdd(oob, 1);
+            continue;
+        }
+        atomicAdd(touch + q, 1);
+        if (f & 2u) {
+            atomicAdd(cov + q, 1);
+            if (f & 4u) atomicAdd(mod + q, 1);
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------
+struct dm_model {
+    int device = 0;
+    int num_cu = 0;
+    hipStream_t stream = nullptr;
+    float* d_wpack = nullptr;
+    float* d_bpack = nullptr;
+    float* d_hpack = nullptr;
+    float* d_scratch = nullptr;
+    float bout[2] = {0, 0};
+    int grid_cap = 0;
+    // staging for host-pointer callers
+    static constexpr int64_t STAGE_WINDOWS = 65536;
+    float* d_x = nullptr;
+    float* d_prob = nullptr;
+    uint8_t* d_cls = nullptr;
+    int64_t stage_rows = 0;  // capacity of d_x in floats
+    // profiling
+    bool profile = false;
+    int precision = DM_PREC_F32;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0, prof_windows = 0;
+};
+
+struct dm_summary {
+    int device = 0;
+    int64_t length = 0;
+    int* d_counts = nullptr;  // touch | cov | mod
+    int* d_oob = nullptr;
+    long long* d_pos = nullptr;
+    unsigned char* d_flags = nullptr;
+    int64_t stage_cap = 0;
+    hipStream_t stream = nullptr;
+};
+
+namespace {
+
+int ensure_stage(dm_model* m, int64_t x_floats) {
+    if (!m->d_prob) {
+        HIP_TRY(hipMalloc(&m->d_prob, sizeof(float) * 2 * dm_model::STAGE_WINDOWS));
+        HIP_TRY(hipMalloc(&m->d_cls, dm_model::STAGE_WINDOWS));
+    }
+    if (x_floats > m->stage_rows) {
+        if (m->d_x) HIP_TRY(hipFree(m->d_x));
+        m->d_x = nullptr;
+        HIP_TRY(hipMalloc(&m->d_x, sizeof(float) * x_floats));
+        m->stage_rows = x_floats;
+    }
+    return DM_OK;
+}
+
+int flush_profile(dm_model* m) {
+    for (size_t i = 0; i < m->events_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(m->events[i].second));
+        HIP_TRY(hipEventElapsedTime(&ms, m->events[i].first, m->events[i].second));
+        m->prof_ms += ms;
+    }
+    m->events_used = 0;
+    return DM_OK;
+}
+
+// launch on device-resident buffers
+int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, float* d_prob, uint8_t* d_cls) {
+    using namespace lstm32;
+    if (n <= 0) return DM_OK;
+    if (m->precision != DM_PREC_F32) return fail(DM_ESTATE, "precision mode %d not available in this build", m->precision);
+    Params p;
+    p.wpack = m->d_wpack;
+    p.bpack = m->d_bpack;
+    p.hpack = m->d_hpack;
+    p.bout0 = m->bout[0];
+    p.bout1 = m->bout[1];
+    p.x = d_x;
+    p.xstride = xstride;
+    p.n = n;
+    p.prob = d_prob;
+    p.cls = d_cls;
+    p.scratch = m->d_scratch;
+    p.ntiles = int((n + TILE_M - 1) / TILE_M);
+    const int grid = std::min(p.ntiles, m->grid_cap);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (m->profile) {
+        if (m->events_used == m->events.size()) {
+            if (m->events.size() >= 4096) {
+                int rc = flush_profile(m);
+                if (rc) return rc;
+            } else {
+                hipEvent_t a, b;
+                HIP_TRY(hipEventCreate(&a));
+                HIP_TRY(hipEventCreate(&b));
+                m->events.emplace_back(a, b);
+            }
+        }
+        e0 = m->events[m->events_used].first;
+        e1 = m->events[m->events_used].second;
+        ++m->events_used;
+        HIP_TRY(hipEventRecord(e0, m->stream));
+    }
+    hipLaunchKernelGGL(bilstm_f32_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
+    HIP_TRY(hipGetLastError());
+    if (m->profile) {
+        HIP_TRY(hipEventRecord(e1, m->stream));
+        ++m->prof_launches;
+        m->prof_windows += n;
+    }
+    return DM_OK;
+}
+
+int predict_common(dm_model* m, const float* x, long long xstride, int64_t x_floats_total, int64_t n,
+                   float* prob, uint8_t* cls, bool windows_materialised) {
+    if (!m) return fail(DM_EINVAL, "null model");
+    if (n < 0) return fail(DM_EINVAL, "negative window count");
+    if (n == 0) return DM_OK;
+    if (!x) return fail(DM_EINVAL, "null input");
+    HIP_TRY(hipSetDevice(m->device));
+    const bool xdev = is_device_ptr(x);
+    const bool pdev = prob ? is_device_ptr(prob) : true;
+    const bool cdev = cls ? is_device_ptr(cls) : true;
+    if (xdev && pdev && cdev) {
+        int rc = launch_bilstm(m, x, xstride, n, prob, cls);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        return DM_OK;
+    }
+    // host buffers: stage through device memory in batches
+    if (!windows_materialised) {
+        // per-read rows: copy the whole row matrix once, classify, copy results back
+        int rc = ensure_stage(m, x_floats_total);
+        if (rc) return rc;
+        const float* dx = x;
+        if (!xdev) {
+            HIP_TRY(hipMemcpyAsync(m->d_x, x, sizeof(float) * x_floats_total, hipMemcpyHostToDevice, m->stream));
+            dx = m->d_x;
+        }
+        for (int64_t off = 0; off < n; off += dm_model::STAGE_WINDOWS) {
+            const int64_t cnt = std::min<int64_t>(dm_model::STAGE_WINDOWS, n - off);
+            float* dp = prob ? (pdev ? prob + 2 * off : m->d_prob) : nullptr;
+            uint8_t* dc = cls ? (cdev ? cls + off : m->d_cls) : nullptr;
+            rc = launch_bilstm(m, dx + off * xstride, xstride, cnt, dp, dc);
+            if (rc) return rc;
+            if (prob && !pdev)
+                HIP_TRY(hipMemcpyAsync(prob + 2 * off, m->d_prob, sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost, m->stream));
+            if (cls && !cdev) HIP_TRY(hipMemcpyAsync(cls + off, m->d_cls, cnt, hipMemcpyDeviceToHost, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+        }
+        return DM_OK;
+    }
+    int rc = ensure_stage(m, int64_t(dm_model::STAGE_WINDOWS) * DM_WINDOW * DM_NFEAT);
+    if (rc) return rc;
+    for (int64_t off = 0; off < n; off += dm_model::STAGE_WINDOWS) {
+        const int64_t cnt = std::min<int64_t>(dm_model::STAGE_WINDOWS, n - off);
+        const float* dx = x + off * xstride;
+        if (!xdev) {
+            HIP_TRY(hipMemcpyAsync(m->d_x, x + off * xstride, sizeof(float) * cnt * DM_WINDOW * DM_NFEAT,
+                                   hipMemcpyHostToDevice, m->stream));
+            dx = m->d_x;
+        }
+        float* dp = prob ? (pdev ? prob + 2 * off : m->d_prob) : nullptr;
+        uint8_t* dc = cls ? (cdev ? cls + off : m->d_cls) : nullptr;
+        rc = launch_bilstm(m, dx, xstride, cnt, dp, dc);
+        if (rc) return rc;
+        if (prob && !pdev)
+            HIP_TRY(hipMemcpyAsync(prob + 2 * off, m->d_prob, sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost, m->stream));
+        if (cls && !cdev) HIP_TRY(hipMemcpyAsync(cls + off, m->d_cls, cnt, hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    return DM_OK;
+}
+
+int model_init(dm_model* m, const float* weights) {
+    using namespace lstm32;
+    HIP_TRY(hipSetDevice(m->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, m->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(DM_EDEVICE, "device %d is %s; this library is built for gfx950 only", m->device, prop.gcnArchName);
+    m->num_cu = prop.multiProcessorCount;
+    m->grid_cap = m->num_cu;  // 120 KB of LDS per workgroup -> one resident workgroup per CU
+    HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    Packed P = pack_weights(weights);
+    m->bout[0] = P.bout[0];
+    m->bout[1] = P.bout[1];
+    HIP_TRY(hipMalloc(&m->d_wpack, P.w.size() * sizeof(float)));
+    HIP_TRY(hipMalloc(&m->d_bpack, P.b.size() * sizeof(float)));
+    HIP_TRY(hipMalloc(&m->d_hpack, P.h.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(m->d_wpack, P.w.data(), P.w.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_bpack, P.b.data(), P.b.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_hpack, P.h.data(), P.h.size() * sizeof(float), hipMemcpyHostToDevice));
+    const size_t scratch_bytes = size_t(m->grid_cap) * SCRATCH_FLOATS_PER_WG * sizeof(float);
+    HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
+    HIP_TRY(hipMemset(m->d_scratch, 0, scratch_bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_f32_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_BYTES)));
+    return DM_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* dm_last_error(void) { return g_err.c_str(); }
+const char* dm_version(void) { return "deepmod_hip 0.1 (gfx950)"; }
+
+int dm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+dm_model* dm_model_create(int device, const float* weights, size_t n_floats, int n_feat, int hidden, int window,
+                          int layers) {
+    if (!weights || n_floats != DM_WEIGHT_FLOATS) {
+        fail(DM_EINVAL, "weights: expected %d floats, got %zu", DM_WEIGHT_FLOATS, n_floats);
+        return nullptr;
+    }
+    if (n_feat != DM_NFEAT || hidden != DM_HIDDEN || window != DM_WINDOW || layers != DM_LAYERS) {
+        fail(DM_EINVAL, "unsupported geometry fnum=%d hidden=%d window=%d layers=%d (built for 7/100/21/3)", n_feat,
+             hidden, window, layers);
+        return nullptr;
+    }
+    dm_model* m = new (std::nothrow) dm_model();
+    if (!m) {
+        fail(DM_ENOMEM, "out of host memory");
+        return nullptr;
+    }
+    m->device = device;
+    if (model_init(m, weights) != DM_OK) {
+        std::string keep = g_err;
+        dm_model_destroy(m);
+        g_err = keep;
+        return nullptr;
+    }
+    return m;
+}
+
+void dm_model_destroy(dm_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (auto& e : m->events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    (void)hipFree(m->d_wpack);
+    (void)hipFree(m->d_bpack);
+    (void)hipFree(m->d_hpack);
+    (void)hipFree(m->d_scratch);
+    (void)hipFree(m->d_x);
+    (void)hipFree(m->d_prob);
+    (void)hipFree(m->d_cls);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int dm_model_set_option(dm_model* m, int key, int64_t value) {
+    if (!m) return fail(DM_EINVAL, "null model");
+    switch (key) {
+        case DM_OPT_PROFILE:
+            m->profile = value != 0;
+            return DM_OK;
+        case DM_OPT_PRECISION:
+            if (value != DM_PREC_F32) return fail(DM_EINVAL, "precision %lld not available in this build", (long long)value);
+            m->precision = int(value);
+            return DM_OK;
+        default:
+            return fail(DM_EINVAL, "unknown option %d", key);
+    }
+}
+
+int dm_predict_windows(dm_model* m, const float* x, int64_t n, float* prob, uint8_t* cls) {
+    return predict_common(m, x, DM_WINDOW * DM_NFEAT, n * DM_WINDOW * DM_NFEAT, n, prob, cls, true);
+}
+
+int dm_predict_read(dm_model* m, const float* rows, int64_t m_rows, int64_t first, int64_t count, float* prob,
+                    uint8_t* cls) {
+    if (!m) return fail(DM_EINVAL, "null model");
+    if (count < 0 || first < DM_WINDOW / 2 || first + count + DM_WINDOW / 2 > m_rows)
+        return fail(DM_EINVAL, "window range [%lld, %lld) +-10 outside the %lld feature rows", (long long)first,
+                    (long long)(first + count), (long long)m_rows);
+    if (count == 0) return DM_OK;
+    if (!rows) return fail(DM_EINVAL, "null input");
+    // window i = rows[first + i - 10 .. first + i + 10]  ->  base pointer at row (first - 10), window stride 7
+    if (is_device_ptr(rows))
+        return predict_common(m, rows + (first - DM_WINDOW / 2) * DM_NFEAT, DM_NFEAT, 0, count, prob, cls, false);
+    // host rows: ship only the rows this call needs
+    const float* base = rows + (first - DM_WINDOW / 2) * DM_NFEAT;
+    return predict_common(m, base, DM_NFEAT, (count + DM_WINDOW - 1) * DM_NFEAT, count, prob, cls, false);
+}
+
+int dm_model_sync(dm_model* m) {
+    if (!m) return fail(DM_EINVAL, "null model");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return DM_OK;
+}
+
+int dm_profile_reset(dm_model* m) {
+    if (!m) return fail(DM_EINVAL, "null model");
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->events_used = 0;
+    m->prof_ms = 0.0;
+    m->prof_launches = 0;
+    m->prof_windows = 0;
+    return DM_OK;
+}
+
+int dm_profile_get(dm_model* m, double* kernel_ms, int64_t* launches, int64_t* windows) {
+    if (!m) return fail(DM_EINVAL, "null model");
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    int rc = flush_profile(m);
+    if (rc) return rc;
+    if (kernel_ms) *kernel_ms = m->prof_ms;
+    if (launches) *launches = m->prof_launches;
+    if (windows) *windows = m->prof_windows;
+    return DM_OK;
+}
+
+void* dm_device_alloc(int device, size_t bytes) {
+    void* p = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        fail(DM_ENOMEM, "hipMalloc(%zu) on device %d failed", bytes, device);
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+int dm_device_free(int device, void* p) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(p));
+    return DM_OK;
+}
+
+int dm_memcpy_h2d(int device, void* dst, const void* src, size_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return DM_OK;
+}
+
+int dm_memcpy_d2h(int device, void* dst, const void* src, size_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return DM_OK;
+}
+
+// ------------------------------------------------------------------------------- summary ----
+dm_summary* dm_summary_create(int device, int64_t length) {
+    if (length <= 0 || length > (int64_t(1) << 33)) {
+        fail(DM_EINVAL, "bad contig length %lld", (long long)length);
+        return nullptr;
+    }
+    dm_summary* s = new (std::nothrow) dm_summary();
+    if (!s) {
+        fail(DM_ENOMEM, "out of host memory");
+        return nullptr;
+    }
+    s->device = device;
+    s->length = length;
+    bool ok = hipSetDevice(device) == hipSuccess &&
+              hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc(&s->d_counts, sizeof(int) * 3 * length) == hipSuccess &&
+              hipMalloc(&s->d_oob, sizeof(int)) == hipSuccess &&
+              hipMemset(s->d_counts, 0, sizeof(int) * 3 * length) == hipSuccess &&
+              hipMemset(s->d_oob, 0, sizeof(int)) == hipSuccess;
+    if (!ok) {
+        fail(DM_EDEVICE, "summary allocation of %lld positions on device %d failed: %s", (long long)length, device,
+             hipGetErrorString(hipGetLastError()));
+        dm_summary_destroy(s);
+        return nullptr;
+    }
+    return s;
+}
+
+void dm_summary_destroy(dm_summary* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipFree(s->d_counts);
+    (void)hipFree(s->d_oob);
+    (void)hipFree(s->d_pos);
+    (void)hipFree(s->d_flags);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int64_t dm_summary_length(const dm_summary* s) { return s ? s->length : 0; }
+
+static int summary_add_impl(dm_summary* s, const int64_t* pos, const uint8_t* flags, const uint8_t* cls, int64_t n) {
+    if (!s) return fail(DM_EINVAL, "null summary");
+    if (n < 0) return fail(DM_EINVAL, "negative count");
+    if (n == 0) return DM_OK;
+    if (!pos || !flags) return fail(DM_EINVAL, "null input");
+    HIP_TRY(hipSetDevice(s->device));
+    const long long* dpos = reinterpret_cast<const long long*>(pos);
+    const unsigned char* dfl = flags;
+    const unsigned char* dcl = cls;
+    const bool pd = is_device_ptr(pos), fd = is_device_ptr(flags), cd = cls ? is_device_ptr(cls) : true;
+    if (!(pd && fd && cd)) {
+        if (n > s->stage_cap) {
+            (void)hipFree(s->d_pos);
+            (void)hipFree(s->d_flags);
+            s->d_pos = nullptr;
+            s->d_flags = nullptr;
+            const int64_t cap = std::max<int64_t>(n, 1 << 20);
+            HIP_TRY(hipMalloc(&s->d_pos, sizeof(long long) * cap));
+            HIP_TRY(hipMalloc(&s->d_flags, 2 * cap));
+            s->stage_cap = cap;
+        }
+        if (!pd) {
+            HIP_TRY(hipMemcpyAsync(s->d_pos, pos, sizeof(long long) * n, hipMemcpyHostToDevice, s->stream));
+            dpos = s->d_pos;
+        }
+        if (!fd) {
+            HIP_TRY(hipMemcpyAsync(s->d_flags, flags, n, hipMemcpyHostToDevice, s->stream));
+            dfl = s->d_flags;
+        }
+        if (cls && !cd) {
+            HIP_TRY(hipMemcpyAsync(s->d_flags + s->stage_cap, cls, n, hipMemcpyHostToDevice, s->stream));
+            dcl = s->d_flags + s->stage_cap;
+        }
+    }
+    const int threads = 256;
+    const int blocks = int(std::min<int64_t>((n + threads - 1) / threads, 2048));
+    hipLaunchKernelGGL(summary_add_kernel, dim3(blocks), dim3(threads), 0, s->stream, s->d_counts,
+                       s->d_counts + s->length, s->d_counts + 2 * s->length, (long long)s->length, dpos, dfl, dcl,
+                       (long long)n, s->d_oob);
+    HIP_TRY(hipGetLastError());
+    return DM_OK;
+}
+
+static int summary_check_oob(dm_summary* s) {
+    int oob = 0;
+    HIP_TRY(hipMemcpyAsync(&oob, s->d_oob, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (oob) {
+        HIP_TRY(hipMemset(s->d_oob, 0, sizeof(int)));
+        return fail(DM_EINVAL, "%d positions outside [0, %lld) were dropped", oob, (long long)s->length);
+    }
+    return DM_OK;
+}
+
+int dm_summary_add(dm_summary* s, const int64_t* pos, const uint8_t* flags, int64_t n) {
+    int rc = summary_add_impl(s, pos, flags, nullptr, n);
+    if (rc || n <= 0) return rc;
+    return summary_check_oob(s);  // synchronous on return (the caller may reuse its buffers)
+}
+
+int dm_summary_add_classified(dm_summary* s, const int64_t* pos, const uint8_t* flags, const uint8_t* cls,
+                              int64_t n) {
+    if (n > 0 && !cls) return fail(DM_EINVAL, "null cls");
+    int rc = summary_add_impl(s, pos, flags, cls, n);
+    if (rc || n <= 0) return rc;
+    return summary_check_oob(s);
+}
+
+int dm_summary_sync(dm_summary* s) {
+    if (!s) return fail(DM_EINVAL, "null summary");
+    HIP_TRY(hipSetDevice(s->device));
+    return summary_check_oob(s);
+}
+
+int dm_summary_fetch(dm_summary* s, int32_t* touch, int32_t* cov, int32_t* mod) {
+    if (!s) return fail(DM_EINVAL, "null summary");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc0 = summary_check_oob(s);
+    if (rc0) return rc0;
+    const size_t bytes = sizeof(int) * s->length;
+    if (touch) HIP_TRY(hipMemcpy(touch, s->d_counts, bytes, hipMemcpyDeviceToHost));
+    if (cov) HIP_TRY(hipMemcpy(cov, s->d_counts + s->length, bytes, hipMemcpyDeviceToHost));
+    if (mod) HIP_TRY(hipMemcpy(mod, s->d_counts + 2 * s->length, bytes, hipMemcpyDeviceToHost));
+    return DM_OK;
+}
+
+void* dm_summary_device_ptr(dm_summary* s) { return s ? s->d_counts : nullptr; }
+
+// ---- RCCL, loaded lazily so single-GPU users never need it ---------------------------------
+namespace {
+struct NcclId {
+    char internal[128];
+};
+typedef int (*fn_getid)(NcclId*);
+typedef int (*fn_init)(void**, int, NcclId, int);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_destroy)(void*);
+typedef const char* (*fn_errstr)(int);
+struct Rccl {
+    void* h = nullptr;
+    fn_getid getid = nullptr;
+    fn_init init = nullptr;
+    fn_allreduce allreduce = nullptr;
+    fn_destroy destroy = nullptr;
+    fn_errstr errstr = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+    if (g_rccl.h) return DM_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names) {
+        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail(DM_ERCCL, "cannot dlopen librccl: %s", dlerror());
+    g_rccl.getid = (fn_getid)dlsym(h, "ncclGetUniqueId");
+    g_rccl.init = (fn_init)dlsym(h, "ncclCommInitRank");
+    g_rccl.allreduce = (fn_allreduce)dlsym(h, "ncclAllReduce");
+    g_rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
+    g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.getid || !g_rccl.init || !g_rccl.allreduce || !g_rccl.destroy)
+        return fail(DM_ERCCL, "librccl is missing required symbols");
+    g_rccl.h = h;
+    return DM_OK;
+}
+}  // namespace
+
+int dm_rccl_unique_id(void* out128) {
+    if (!out128) return fail(DM_EINVAL, "null id buffer");
+    int rc = load_rccl();
+    if (rc) return rc;
+    NcclId id;
+    int e = g_rccl.getid(&id);
+    if (e) return fail(DM_ERCCL, "ncclGetUniqueId: %s", g_rccl.errstr ? g_rccl.errstr(e) : "error");
+    std::memcpy(out128, &id, 128);
+    return DM_OK;
+}
+
+int dm_summary_reduce_rccl(dm_summary* s, const void* unique_id128, int rank, int nranks) {
+    if (!s || !unique_id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(DM_EINVAL, "bad reduce arguments");
+    int rc = load_rccl();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    NcclId id;
+    std::memcpy(&id, unique_id128, 128);
+    void* comm = nullptr;
+    int e = g_rccl.init(&comm, nranks, id, rank);
+    if (e) return fail(DM_ERCCL, "ncclCommInitRank: %s", g_rccl.errstr ? g_rccl.errstr(e) : "error");
+    // one in-place sum over touch|cov|mod (int32 = ncclInt32 (2), ncclSum (0)); integer sum is order independent
+    e = g_rccl.allreduce(s->d_counts, s->d_counts, size_t(3) * s->length, 2, 0, comm, s->stream);
+    hipError_t he = hipStreamSynchronize(s->stream);
+    g_rccl.destroy(comm);
+    if (e) return fail(DM_ERCCL, "ncclAllReduce: %s", g_rccl.errstr ? g_rccl.errstr(e) : "error");
+    if (he != hipSuccess) return fail(DM_EDEVICE, "stream sync after all-reduce: %s", hipGetErrorString(he));
+    return DM_OK;
+}
+
+}  // extern "C"

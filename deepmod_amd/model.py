@@ -1,0 +1,277 @@
+"""Host-side model object over the C ABI: weights -> canonical blob -> dm_model, and the
+TF1-Session-shaped adapter that makes the build's `mPredict1` a behavioural twin of the
+reference's (bin/DeepMod_scripts/myDetect.py:805-820).
+
+Mirrors, for the inference path only:
+  * myMultiBiRNN.mCreateSession(num_input, num_hidden, timesteps, moptions)
+        (bin/DeepMod_scripts/myMultiBiRNN.py:21-91) -> same 12-tuple arity, handles are tokens
+  * tf.Session / tf.train.import_meta_graph / Saver.restore / tf.train.latest_checkpoint as used at
+        bin/DeepMod_scripts/myDetect.py:951-956 ("load tensors by variable name")
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _lib, tfbundle
+from .synth import HEAD_B, HEAD_W, cell_name
+
+NFEAT, HID, WIN, LAYERS = 7, 100, 21, 3
+
+
+def flatten_weights(tensors: Dict[str, np.ndarray], nfeat: int = NFEAT, hidden: int = HID) -> np.ndarray:
+    """Canonical flat blob expected by dm_model_create (include/deepmod_hip.h)."""
+    parts = []
+    for direction in ("fw", "bw"):
+        for layer in range(LAYERS):
+            kern = np.asarray(tensors[cell_name(direction, layer, "kernel")], dtype=np.float32)
+            bias = np.asarray(tensors[cell_name(direction, layer, "bias")], dtype=np.float32)
+            kin = nfeat if layer == 0 else hidden
+            if kern.shape != (kin + hidden, 4 * hidden) or bias.shape != (4 * hidden,):
+                raise ValueError("unexpected shape for %s layer %d: %s / %s" % (direction, layer, kern.shape, bias.shape))
+            parts += [kern.ravel(), bias.ravel()]
+    head_w = np.asarray(tensors[HEAD_W], dtype=np.float32)
+    head_b = np.asarray(tensors[HEAD_B], dtype=np.float32)
+    if head_w.shape != (2 * hidden, 2) or head_b.shape != (2,):
+        raise ValueError("unexpected head shapes %s / %s" % (head_w.shape, head_b.shape))
+    parts += [head_w.ravel(), head_b.ravel()]
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+
+
+class DeviceArray:
+    """A typed block of device memory owned through the C ABI (no torch, no hip-python)."""
+
+    def __init__(self, shape, dtype, device: int = 0):
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.device = device
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        lib = _lib.load()
+        self.ptr = lib.dm_device_alloc(device, max(self.nbytes, 1))
+        if not self.ptr:
+            raise _lib.DeepModHipError(_lib.last_error())
+
+    @classmethod
+    def from_host(cls, arr: np.ndarray, device: int = 0) -> "DeviceArray":
+        arr = np.ascontiguousarray(arr)
+        out = cls(arr.shape, arr.dtype, device)
+        _lib.check(_lib.load().dm_memcpy_h2d(device, out.ptr, arr.ctypes.data, arr.nbytes))
+        return out
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            _lib.check(_lib.load().dm_memcpy_d2h(self.device, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            _lib.load().dm_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, DeviceArray):
+        return a.ptr
+    return a.ctypes.data
+
+
+class BiLSTMModel:
+    """One dm_model on one GPU (one per process, like the reference's one TF session per process)."""
+
+    def __init__(self, tensors: Dict[str, np.ndarray], device: int = 0):
+        self._lib = _lib.load()
+        self.device = device
+        flat = flatten_weights(tensors)
+        self._h = self._lib.dm_model_create(device, flat.ctypes.data, flat.size, NFEAT, HID, WIN, LAYERS)
+        if not self._h:
+            raise _lib.DeepModHipError("dm_model_create: " + _lib.last_error())
+
+    @classmethod
+    def from_checkpoint(cls, prefix: str, device: int = 0) -> "BiLSTMModel":
+        return cls(tfbundle.load_bundle(prefix), device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dm_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- options / profiling --------------------------------------------------------------
+    def set_option(self, key: int, value: int):
+        _lib.check(self._lib.dm_model_set_option(self._h, key, value))
+
+    def profile_reset(self):
+        _lib.check(self._lib.dm_profile_reset(self._h))
+
+    def profile_get(self) -> Tuple[float, int, int]:
+        ms = ctypes.c_double()
+        launches = ctypes.c_int64()
+        windows = ctypes.c_int64()
+        _lib.check(self._lib.dm_profile_get(self._h, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(windows)))
+        return ms.value, launches.value, windows.value
+
+    def sync(self):
+        _lib.check(self._lib.dm_model_sync(self._h))
+
+    # -- inference ------------------------------------------------------------------------
+    def predict_windows(self, x, prob=None, cls=None, want_prob: bool = True):
+        """x: float[n,21,7] numpy (any float dtype; cast to fp32 like the TF placeholder feed) or a
+        DeviceArray.  Returns (prob float32[n,2] or None, cls uint8[n])."""
+        if isinstance(x, DeviceArray):
+            n = x.shape[0]
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            if x.ndim != 3 or x.shape[1:] != (WIN, NFEAT):
+                raise ValueError("expected [n,%d,%d] windows, got %s" % (WIN, NFEAT, x.shape))
+            n = x.shape[0]
+        if cls is None:
+            cls = np.empty(n, np.uint8)
+        if prob is None and want_prob:
+            prob = np.empty((n, 2), np.float32)
+        _lib.check(self._lib.dm_predict_windows(self._h, _ptr(x), n, _ptr(prob), _ptr(cls)))
+        return prob, cls
+
+    def predict_read(self, rows, first: int, count: int, prob=None, cls=None, want_prob: bool = True):
+        """Classify windows centred on rows[first .. first+count) of a per-read feature matrix
+        rows float[m,7] (windows are assembled on the device)."""
+        if isinstance(rows, DeviceArray):
+            m = rows.shape[0]
+        else:
+            rows = np.ascontiguousarray(rows, dtype=np.float32)
+            if rows.ndim != 2 or rows.shape[1] != NFEAT:
+                raise ValueError("expected [m,%d] feature rows, got %s" % (NFEAT, rows.shape))
+            m = rows.shape[0]
+        if cls is None:
+            cls = np.empty(count, np.uint8)
+        if prob is None and want_prob:
+            prob = np.empty((count, 2), np.float32)
+        _lib.check(self._lib.dm_predict_read(self._h, _ptr(rows), m, first, count, _ptr(prob), _ptr(cls)))
+        return prob, cls
+
+
+# ---------------------------------------------------------------------------------------------
+# TF1-shaped adapter (the drop-in seam of SURVEY.md 8b)
+# ---------------------------------------------------------------------------------------------
+class _Token:
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return "<deepmod_amd %s>" % self.name
+
+
+class Session:
+    """Stands in for tf.Session in `sp_options['rnn'] = (sess, X, Y, init_l, mfpred)`
+    (reference myDetect.py:972).  `run(init_l)` is a no-op (it only resets tf.metrics local
+    variables); `run([mfpred], feed_dict={X: x, Y: y})` returns
+    [int64[n]] exactly like the reference call at myDetect.py:816-820 (Y is accepted and
+    ignored, quirk Q7).  `run([prediction], ...)` additionally exposes the probabilities."""
+
+    def __init__(self, graph: "Graph", device: int = 0):
+        self.graph = graph
+        self.device = device
+        self.model: Optional[BiLSTMModel] = None
+
+    def restore(self, prefix: str):
+        self.model = BiLSTMModel.from_checkpoint(prefix, self.device)
+
+    def load_tensors(self, tensors: Dict[str, np.ndarray]):
+        self.model = BiLSTMModel(tensors, self.device)
+
+    def run(self, fetches, feed_dict=None):
+        single = not isinstance(fetches, (list, tuple))
+        flist = [fetches] if single else list(fetches)
+        if all(f is self.graph.init_l or f is self.graph.init for f in flist):
+            return None if single else [None] * len(flist)
+        if self.model is None:
+            raise _lib.DeepModHipError("Session.run before restore(): no weights loaded")
+        if feed_dict is None or self.graph.X not in feed_dict:
+            raise ValueError("feed_dict must provide X")
+        x = np.asarray(feed_dict[self.graph.X])
+        prob, cls = self.model.predict_windows(x, want_prob=any(f is self.graph.prediction for f in flist))
+        out = []
+        for f in flist:
+            if f is self.graph.mfpred:
+                out.append(cls.astype(np.int64))
+            elif f is self.graph.prediction:
+                out.append(prob)
+            else:
+                raise ValueError("cannot fetch %r (inference-only build)" % (f,))
+        return out[0] if single else out
+
+    def close(self):
+        if self.model is not None:
+            self.model.close()
+            self.model = None
+
+
+class Graph:
+    def __init__(self, num_input, num_hidden, timesteps):
+        if (num_input, num_hidden, timesteps) != (NFEAT, HID, WIN):
+            raise ValueError("this build supports fnum=7 hidden=100 windowsize=21 only (got %s)" %
+                             ((num_input, num_hidden, timesteps),))
+        self.X = _Token("X")
+        self.Y = _Token("Y")
+        self.init = _Token("init")
+        self.init_l = _Token("init_l")
+        self.mfpred = _Token("mfpred")
+        self.prediction = _Token("prediction")
+        self.saver = Saver()
+
+
+class Saver:
+    """`new_saver.restore(sess, prefix)` -> load tensors by variable name."""
+
+    def restore(self, sess: Session, save_path: str):
+        if save_path is None:
+            raise ValueError("no checkpoint found (latest_checkpoint returned None)")
+        sess.restore(save_path)
+
+
+_last_graph: Optional[Graph] = None
+
+
+def mCreateSession(num_input, num_hidden, timesteps, moptions):
+    """Same arity/positions as the reference's 12-tuple
+    (init, init_l, loss_op, accuracy, train_op, X, Y, saver, auc_op, mpre, mspf, mfpred);
+    training-side entries are None (inference-only build)."""
+    global _last_graph
+    if moptions.get("outputlayer", "") in ("sigmoid",):
+        raise ValueError("--outputlayer sigmoid is not used by any shipped model and is not built")
+    g = Graph(num_input, num_hidden, timesteps)
+    _last_graph = g
+    return (g.init, g.init_l, None, None, None, g.X, g.Y, g.saver, None, None, None, g.mfpred)
+
+
+def import_meta_graph(meta_path: str) -> Saver:
+    """The .meta is not needed to run (the graph is compiled in); its presence is still checked
+    so a wrong --modfile fails as early as it does in the reference."""
+    if not os.path.exists(meta_path) and not os.path.exists(meta_path[:-5] + ".index"):
+        raise FileNotFoundError(meta_path)
+    return Saver()
+
+
+def new_session(device: int = 0) -> Session:
+    if _last_graph is None:
+        raise RuntimeError("call mCreateSession first")
+    return Session(_last_graph, device)
+
+
+latest_checkpoint = tfbundle.latest_checkpoint

@@ -1,0 +1,111 @@
+"""Per-position (coverage, mod-count) summary on the GPU and the BED writer.
+
+Counterpart of the accumulation loop and writer of the reference's sum_handler
+(bin/DeepMod_scripts/myDetect.py:1089-1120): dense int32 counters per contig x strand
+(`touch`, `cov`, `mod`) updated with integer atomics, so the result is independent of read order
+and of how reads were sharded over GPUs; the cross-GPU merge is one integer all-reduce (the
+additive merge the reference does across processes with DeepMod_tools/sum_chr_mod.py:47-52).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .model import DeviceArray, _ptr
+
+FLAG_IS_BASE = 1   # refbase == Base and refbase not in '-Nn'   (myDetect.py:1091-1092)
+FLAG_NOT_GAP = 2   # readbase != '-'                            (myDetect.py:1097)
+FLAG_MOD = 4       # mod_pred == 1                              (myDetect.py:1099)
+
+
+class PositionSummary:
+    def __init__(self, length: int, device: int = 0):
+        self._lib = _lib.load()
+        self.length = int(length)
+        self.device = device
+        self._h = self._lib.dm_summary_create(device, self.length)
+        if not self._h:
+            raise _lib.DeepModHipError("dm_summary_create: " + _lib.last_error())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dm_summary_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add(self, pos, flags, n: Optional[int] = None):
+        if not isinstance(pos, DeviceArray):
+            pos = np.ascontiguousarray(pos, dtype=np.int64)
+            flags = np.ascontiguousarray(flags, dtype=np.uint8)
+            n = pos.size
+        _lib.check(self._lib.dm_summary_add(self._h, _ptr(pos), _ptr(flags), n))
+
+    def add_classified(self, pos, flags, cls, n: Optional[int] = None):
+        if not isinstance(pos, DeviceArray):
+            pos = np.ascontiguousarray(pos, dtype=np.int64)
+            n = pos.size
+        if not isinstance(flags, DeviceArray):
+            flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        if not isinstance(cls, DeviceArray):
+            cls = np.ascontiguousarray(cls, dtype=np.uint8)
+        _lib.check(self._lib.dm_summary_add_classified(self._h, _ptr(pos), _ptr(flags), _ptr(cls), n))
+
+    def sync(self):
+        _lib.check(self._lib.dm_summary_sync(self._h))
+
+    def fetch(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        touch = np.empty(self.length, np.int32)
+        cov = np.empty(self.length, np.int32)
+        mod = np.empty(self.length, np.int32)
+        _lib.check(self._lib.dm_summary_fetch(self._h, touch.ctypes.data, cov.ctypes.data, mod.ctypes.data))
+        return touch, cov, mod
+
+    # -- multi-GPU merges ------------------------------------------------------------------
+    def all_reduce_rccl(self, unique_id: bytes, rank: int, nranks: int):
+        """Native path: RCCL all-reduce(sum, int32) on the counters, communicator built from a
+        128-byte unique id that rank 0 obtained from `rccl_unique_id()` and shared out of band."""
+        buf = ctypes.create_string_buffer(unique_id, 128)
+        _lib.check(self._lib.dm_summary_reduce_rccl(self._h, buf, rank, nranks))
+
+    def all_reduce_torch(self, dist):
+        """Same merge through an already initialised torch.distributed process group (backend nccl
+        == RCCL): the counters are aliased as a torch tensor via __cuda_array_interface__."""
+        import torch
+        ptr = self._lib.dm_summary_device_ptr(self._h)
+
+        class _Alias:
+            __cuda_array_interface__ = {"shape": (3 * self.length,), "typestr": "<i4", "data": (int(ptr), False),
+                                        "version": 2, "strides": None}
+        self.sync()
+        t = torch.as_tensor(_Alias(), device=torch.device("cuda", self.device))
+        if t.data_ptr() != int(ptr):
+            raise _lib.DeepModHipError("torch did not alias the summary buffer")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+
+
+def rccl_unique_id() -> bytes:
+    buf = ctypes.create_string_buffer(128)
+    _lib.check(_lib.load().dm_rccl_unique_id(buf))
+    return buf.raw
+
+
+def bed_lines(chrom: str, strand: str, base: str, touch: np.ndarray, cov: np.ndarray, mod: np.ndarray) -> bytes:
+    """BED text exactly as the reference writes it (myDetect.py:1112-1120): one line per position
+    whose key was created (touch > 0), sorted by position, single spaces, trailing space before the
+    newline, column 5 = min(cov, 1000), pct = trunc(100*mod/max(cov,1))."""
+    idx = np.flatnonzero(touch > 0)
+    out = []
+    for pos, cv, md in zip(idx.tolist(), cov[idx].tolist(), mod[idx].tolist()):
+        pct = "%d" % (100 * md / (cv if cv > 0 else 1))
+        out.append(" ".join([chrom, str(pos), str(pos + 1), base, str(1000 if cv > 1000 else cv), strand,
+                             str(pos), str(pos + 1), "0,0,0", str(cv), pct, str(md), "\n"]))
+    return "".join(out).encode("ascii")

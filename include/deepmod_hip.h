@@ -1,0 +1,139 @@
+/*
+ * deepmod_hip.h — C ABI of libdeepmod_hip.so: the MI355X (gfx950) implementation of DeepMod's
+ * per-read BiLSTM modification-calling hot path and its per-position summary.
+ *
+ * Plain pointers and sizes only.  Every function returns 0 on success or a negative DM_E* code;
+ * the message of the last failure on the calling thread is available from dm_last_error().
+ * A handle is single-owner (one process per GPU, as the reference runs one TF session per
+ * process: bin/DeepMod_scripts/myDetect.py:948-956, :1177-1180); calls are synchronous on return
+ * unless the name says _async.  The caller owns every buffer it passes; the library keeps no host
+ * pointer after a call returns.
+ *
+ * Reference interfaces replaced (all under /root/reference/):
+ *   dm_model_create / dm_model_destroy
+ *        myMultiBiRNN.mCreateSession            bin/DeepMod_scripts/myMultiBiRNN.py:21-91
+ *        tf.Session + Saver.restore             bin/DeepMod_scripts/myDetect.py:950-956
+ *   dm_predict_windows
+ *        sess.run([mfpred], feed_dict={X, Y})   bin/DeepMod_scripts/myDetect.py:814-820
+ *        (graph: myMultiBiRNN.py:38-61; prediction=softmax :59, mfpred=argmax :61)
+ *   dm_predict_read
+ *        window assembly tx[mind-10:mind+11]    bin/DeepMod_scripts/myDetect.py:794-803
+ *        + the sess.run above, fused on device
+ *   dm_summary_create / _add / _add_read / _fetch / _destroy
+ *        sum_handler's per-base accumulation    bin/DeepMod_scripts/myDetect.py:1089-1100
+ *   dm_summary_reduce_rccl
+ *        cross-process additive merge           DeepMod_tools/sum_chr_mod.py:47-52
+ */
+#ifndef DEEPMOD_HIP_H
+#define DEEPMOD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM_OK 0
+#define DM_EINVAL (-1)   /* bad argument */
+#define DM_EDEVICE (-2)  /* HIP runtime error / no gfx950 device */
+#define DM_ENOMEM (-3)   /* allocation failed */
+#define DM_ESTATE (-4)   /* handle in wrong state */
+#define DM_ERCCL (-5)    /* RCCL could not be loaded or failed */
+
+/* model geometry fixed by the shipped checkpoints */
+#define DM_NFEAT 7
+#define DM_HIDDEN 100
+#define DM_WINDOW 21
+#define DM_LAYERS 3
+#define DM_WEIGHT_FLOATS 408402
+
+/* dm_model_set_option keys */
+#define DM_OPT_PROFILE 1   /* 1: bracket every kernel launch with HIP events on the model's stream */
+#define DM_OPT_PRECISION 2 /* DM_PREC_* */
+#define DM_PREC_F32 0      /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
+#define DM_PREC_F16X3 1    /* split-f16 MFMA, 3 products per f32 product */
+
+typedef struct dm_model dm_model;
+typedef struct dm_summary dm_summary;
+
+const char* dm_last_error(void);
+const char* dm_version(void);
+
+/* number of visible gfx950 devices (0 if none / HIP unusable) */
+int dm_device_count(void);
+
+/*
+ * Build a model on `device` from the canonical flat weight blob (DM_WEIGHT_FLOATS floats, host):
+ *   for d in (fw, bw): for l in 0..2: kernel[K_l][400] row-major (K_0 = 107, else 200; columns
+ *   i|j|f|o as TF BasicLSTMCell), bias[400];  then head W[200][2], head b[2].
+ * The forget bias (+1.0) is NOT pre-added by the caller.  Returns NULL on failure.
+ */
+dm_model* dm_model_create(int device, const float* weights, size_t n_floats, int n_feat, int hidden,
+                          int window, int layers);
+void dm_model_destroy(dm_model* m);
+int dm_model_set_option(dm_model* m, int key, int64_t value);
+
+/*
+ * Classify n windows.  x: [n][21][7] fp32 C-contiguous, host OR device memory (detected).
+ * prob: [n][2] fp32 or NULL; cls: [n] u8 (argmax, ties -> 0) or NULL; each may be host or device.
+ * n == 0 is a no-op.
+ */
+int dm_predict_windows(dm_model* m, const float* x, int64_t n, float* prob, uint8_t* cls);
+
+/*
+ * Classify `count` consecutive windows of one read: window i is rows[first+i-10 .. first+i+10]
+ * of the per-read feature matrix rows [m][7] (fp32, host or device); the caller guarantees
+ * first-10 >= 0 and first+count+10 <= m (DeepMod pads 100 rows each side).  Windows are
+ * assembled on the device.
+ */
+int dm_predict_read(dm_model* m, const float* rows, int64_t m_rows, int64_t first, int64_t count,
+                    float* prob, uint8_t* cls);
+
+/* block until all work queued on the model's stream has finished */
+int dm_model_sync(dm_model* m);
+
+/* profiling (DM_OPT_PROFILE=1): summed HIP-event time and launch count of the BiLSTM kernel since
+ * the last reset; dm_profile_get synchronises the stream first. */
+int dm_profile_reset(dm_model* m);
+int dm_profile_get(dm_model* m, double* kernel_ms, int64_t* launches, int64_t* windows);
+
+/* device-memory helpers so a host language without a HIP binding can keep inputs resident */
+void* dm_device_alloc(int device, size_t bytes);
+int dm_device_free(int device, void* p);
+int dm_memcpy_h2d(int device, void* dst, const void* src, size_t bytes);
+int dm_memcpy_d2h(int device, void* dst, const void* src, size_t bytes);
+
+/* ------------------------------------------------------------------ per-position summary -- */
+/*
+ * Dense per-position counters for one contig x strand of `length` reference positions:
+ * touch (rows with refbase == Base: the reference creates the BED key before testing
+ * readbase, myDetect.py:1093-1094), cov (readbase != '-'), mod (mod_pred == 1), all int32.
+ */
+dm_summary* dm_summary_create(int device, int64_t length);
+void dm_summary_destroy(dm_summary* s);
+int64_t dm_summary_length(const dm_summary* s);
+
+/* flags bit0: refbase == Base (and not '-','N','n'); bit1: readbase != '-'; bit2: mod_pred == 1.
+ * pos / flags: [n], host or device. */
+int dm_summary_add(dm_summary* s, const int64_t* pos, const uint8_t* flags, int64_t n);
+/* same, with bit2 taken from the classifier output cls[i] == 1 (the per-base scatter of
+ * myDetect.py:829-831 fused with the accumulation); flags' own bit2 is ignored. */
+int dm_summary_add_classified(dm_summary* s, const int64_t* pos, const uint8_t* flags, const uint8_t* cls,
+                              int64_t n);
+int dm_summary_sync(dm_summary* s);
+
+/* sum this summary across all ranks of an RCCL communicator created from `unique_id`
+ * (128 bytes from dm_rccl_unique_id on rank 0), result valid on every rank. */
+int dm_rccl_unique_id(void* out128);
+int dm_summary_reduce_rccl(dm_summary* s, const void* unique_id128, int rank, int nranks);
+
+/* copy counters to host arrays of `length` int32 each (any may be NULL) */
+int dm_summary_fetch(dm_summary* s, int32_t* touch, int32_t* cov, int32_t* mod);
+/* raw device pointers (3 * length int32: touch | cov | mod) for callers that run their own collective */
+void* dm_summary_device_ptr(dm_summary* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPMOD_HIP_H */

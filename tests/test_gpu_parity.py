@@ -1,0 +1,155 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle and the golden
+fixtures.  Tolerance from BASELINE.json north_star: per-base probabilities within 1e-4 (fp32),
+classes exact away from near ties (|p1-0.5| < 1e-4)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from deepmod_amd import model, synth
+from oracle import oracle_np
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _check(prob, cls, ref_prob, ref_cls):
+    assert prob.shape == ref_prob.shape
+    err = float(np.abs(prob - ref_prob).max()) if len(prob) else 0.0
+    assert err <= TOL, "max|dp| = %g" % err
+    near = np.abs(ref_prob[:, 1] - 0.5) < TOL
+    bad = (cls.astype(np.int64) != ref_cls) & ~near
+    assert not bad.any(), "%d class flips away from ties" % int(bad.sum())
+    assert np.allclose(prob.sum(axis=1), 1.0, atol=1e-6)
+    return err
+
+
+@pytest.fixture(scope="module")
+def models(gpu_device):
+    cache = {}
+
+    def get(seed, scale):
+        key = (seed, scale)
+        if key not in cache:
+            w = synth.synthetic_weights(seed, scale)
+            cache[key] = (w, model.BiLSTMModel(w, device=gpu_device))
+        return cache[key]
+    yield get
+    for _, m in cache.values():
+        m.close()
+
+
+FIX = sorted(glob.glob(os.path.join(GOLDEN, "bilstm_*.npz")))
+
+
+@pytest.mark.parametrize("path", FIX, ids=[os.path.basename(p)[7:-4] for p in FIX])
+def test_golden_reference_graph(path, models):
+    g = np.load(path)
+    w, m = models(int(g["seed_w"]), float(g["scale"]))
+    prob, cls = m.predict_windows(g["X"])
+    _check(prob, cls, g["prob"], g["cls"])
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 127, 128, 129, 255, 1000, 4097])
+@pytest.mark.parametrize("scale", [1.0, 4.0])
+def test_vs_oracle_ragged_sizes(n, scale, models):
+    w, m = models(21, scale)
+    x = synth.synthetic_windows(n, seed=100 + n)
+    prob, cls = m.predict_windows(x)
+    ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
+    _check(prob, cls, ref_prob, ref_cls)
+
+
+def test_empty_batch(models):
+    _, m = models(21, 1.0)
+    prob, cls = m.predict_windows(np.zeros((0, 21, 7), np.float32))
+    assert prob.shape == (0, 2) and cls.shape == (0,)
+
+
+def test_float64_feed_is_cast_like_the_placeholder(models):
+    """mPredict1 feeds float64 windows (myDetect.py:802); the placeholder casts to fp32."""
+    w, m = models(21, 1.0)
+    x = synth.synthetic_windows(200, seed=4).astype(np.float64)
+    prob, cls = m.predict_windows(x)
+    ref_prob, ref_cls = oracle_np.predict_windows_c(w, x.astype(np.float32))
+    _check(prob, cls, ref_prob, ref_cls)
+
+
+def test_extreme_inputs_saturate_cleanly(models):
+    """Signal clipped to +-5 MAD, raw length up to thousands of samples, all-zero padding rows."""
+    w, m = models(22, 4.0)
+    x = synth.synthetic_windows(256, seed=8)
+    x[:64, :, 6] = 5000.0
+    x[64:128, :, 4] = -5.0
+    x[128:192] = 0.0
+    prob, cls = m.predict_windows(x)
+    assert np.isfinite(prob).all()
+    ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
+    _check(prob, cls, ref_prob, ref_cls)
+
+
+def test_device_resident_and_host_paths_agree(models, gpu_device):
+    w, m = models(21, 4.0)
+    x = synth.synthetic_windows(70000, seed=77)  # > one 65,536-window staging batch
+    prob_h, cls_h = m.predict_windows(x)
+    dx = model.DeviceArray.from_host(x, gpu_device)
+    dp = model.DeviceArray((x.shape[0], 2), np.float32, gpu_device)
+    dc = model.DeviceArray((x.shape[0],), np.uint8, gpu_device)
+    m.predict_windows(dx, prob=dp, cls=dc)
+    assert np.array_equal(dp.to_host(), prob_h)
+    assert np.array_equal(dc.to_host(), cls_h)
+    # determinism: same input, same bits
+    prob2, cls2 = m.predict_windows(x)
+    assert np.array_equal(prob2, prob_h) and np.array_equal(cls2, cls_h)
+    # sample against the oracle
+    idx = np.random.default_rng(0).choice(x.shape[0], 2000, replace=False)
+    ref_prob, ref_cls = oracle_np.predict_windows_c(w, x[idx])
+    _check(prob_h[idx], cls_h[idx], ref_prob, ref_cls)
+
+
+def test_predict_read_equals_materialised_windows(models):
+    """On-device window assembly (dm_predict_read) == materialised tx[mind-10:mind+11] windows
+    (reference myDetect.py:794-803)."""
+    w, m = models(21, 4.0)
+    rng = np.random.default_rng(5)
+    nev = 700
+    rows = np.zeros((nev + 200, 7), np.float32)
+    rows[100:-100] = synth.synthetic_windows(nev, seed=3)[:, 0, :]
+    first, count = 100, nev
+    prob_r, cls_r = m.predict_read(rows, first, count)
+    xw = np.stack([rows[first + i - 10:first + i + 11] for i in range(count)])
+    prob_w, cls_w = m.predict_windows(xw)
+    assert np.array_equal(prob_r, prob_w) and np.array_equal(cls_r, cls_w)
+    ref_prob, ref_cls = oracle_np.predict_windows_c(w, xw)
+    _check(prob_r, cls_r, ref_prob, ref_cls)
+
+
+def test_bad_arguments_raise(models, hip_lib):
+    _, m = models(21, 1.0)
+    with pytest.raises(ValueError):
+        m.predict_windows(np.zeros((4, 20, 7), np.float32))
+    from deepmod_amd import _lib
+    with pytest.raises(_lib.DeepModHipError):
+        m.predict_read(np.zeros((50, 7), np.float32), 5, 10)  # first - 10 < 0
+
+
+def test_session_adapter_matches_reference_call_forms(models, tmp_path, gpu_device):
+    """sess.run(init_l); sess.run([mfpred], feed_dict={X: x, Y: y})[0] -> int64[n]
+    (reference myDetect.py:805, :816-820), restoring by variable name from a TF bundle."""
+    prefix = str(tmp_path / "mod_train_synth")
+    w = synth.write_synthetic_checkpoint(prefix, seed=33, scale=4.0)
+    _, init_l, _, _, _, X, Y, _, _, _, _, mfpred = model.mCreateSession(7, 100, 21, {"outputlayer": ""})
+    sess = model.new_session(gpu_device)
+    saver = model.import_meta_graph(prefix + ".meta")
+    saver.restore(sess, model.latest_checkpoint(str(tmp_path)))
+    assert sess.run(init_l) is None
+    x = synth.synthetic_windows(600, seed=12).astype(np.float64)
+    y = np.zeros((600, 2), int)
+    out = sess.run([mfpred], feed_dict={X: x, Y: y})[0]
+    assert out.dtype == np.int64 and out.shape == (600,)
+    ref_prob, ref_cls = oracle_np.predict_windows_c(w, x.astype(np.float32))
+    near = np.abs(ref_prob[:, 1] - 0.5) < TOL
+    assert np.array_equal(out[~near], ref_cls[~near])
+    sess.close()

@@ -1,0 +1,88 @@
+"""GPU (-m gpu): dense per-position summary (integer, bit-exact) vs the oracle restatement of
+sum_handler's accumulation (myDetect.py:1089-1100), plus the 1-rank RCCL reduce."""
+import numpy as np
+import pytest
+
+from deepmod_amd import model, summary
+from oracle import oracle_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_bases(n, length, seed):
+    rng = np.random.default_rng(seed)
+    pos = rng.integers(0, length, n).astype(np.int64)
+    pos[: n // 2] = np.sort(pos[: n // 2])            # read-like sorted runs
+    pos[n // 2: n // 2 + 5000] = 12345 % length        # heavy collisions on one position
+    flags = rng.integers(0, 8, n).astype(np.uint8)
+    return pos, flags
+
+
+def _oracle(length, pos, flags):
+    t = np.zeros(length, np.int32); c = np.zeros(length, np.int32); m = np.zeros(length, np.int32)
+    oracle_np.summary_add_c(t, c, m, pos, flags)
+    return t, c, m
+
+
+@pytest.mark.parametrize("n,length", [(1, 10), (1000, 97), (200000, 50000), (3000000, 4641652)])
+def test_summary_matches_oracle_bit_exact(n, length, gpu_device):
+    pos, flags = _random_bases(n, length, seed=n)
+    s = summary.PositionSummary(length, gpu_device)
+    half = n // 2
+    s.add(pos[:half], flags[:half])      # two calls: accumulation persists across calls
+    s.add(pos[half:], flags[half:])
+    got = s.fetch()
+    want = _oracle(length, pos, flags)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    s.close()
+
+
+def test_summary_classified_device_buffers(gpu_device):
+    n, length = 65536, 100000
+    pos, flags = _random_bases(n, length, seed=3)
+    cls = (np.random.default_rng(9).random(n) < 0.3).astype(np.uint8)
+    s = summary.PositionSummary(length, gpu_device)
+    s.add_classified(model.DeviceArray.from_host(pos, gpu_device), model.DeviceArray.from_host(flags, gpu_device),
+                     model.DeviceArray.from_host(cls, gpu_device), n)
+    got = s.fetch()
+    want = _oracle(length, pos, (flags & 3) | (cls << 2))
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+def test_summary_rejects_out_of_range(gpu_device):
+    from deepmod_amd import _lib
+    s = summary.PositionSummary(100, gpu_device)
+    with pytest.raises(_lib.DeepModHipError):
+        s.add(np.array([5, 100], np.int64), np.array([1, 1], np.uint8))
+    t, c, m = s.fetch()
+    assert t[5] == 1 and t.sum() == 1
+
+
+def test_empty_add_is_noop(gpu_device):
+    s = summary.PositionSummary(10, gpu_device)
+    s.add(np.zeros(0, np.int64), np.zeros(0, np.uint8))
+    assert s.fetch()[0].sum() == 0
+
+
+def test_rccl_all_reduce_single_rank(gpu_device):
+    """nranks = 1 exercises dlopen(librccl), communicator setup and the int32 all-reduce call."""
+    s = summary.PositionSummary(1000, gpu_device)
+    pos, flags = _random_bases(5000, 1000, seed=1)
+    s.add(pos, flags)
+    before = s.fetch()
+    s.all_reduce_rccl(summary.rccl_unique_id(), 0, 1)
+    after = s.fetch()
+    for b, a in zip(before, after):
+        assert np.array_equal(a, b)
+
+
+def test_bed_bytes_from_gpu_counts(gpu_device):
+    s = summary.PositionSummary(50, gpu_device)
+    #            pos flags: C covered+mod, C covered, C deletion only, non-C
+    s.add(np.array([7, 7, 7, 9, 20], np.int64), np.array([7, 3, 3, 1, 6], np.uint8))
+    t, c, m = s.fetch()
+    bed = summary.bed_lines("chrS", "+", "C", t, c, m)
+    assert bed == (b"chrS 7 8 C 3 + 7 8 0,0,0 3 33 1 \n"
+                   b"chrS 9 10 C 0 + 9 10 0,0,0 0 0 0 \n")

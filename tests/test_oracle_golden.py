@@ -1,0 +1,90 @@
+"""CPU: the oracle (C + numpy) against the golden vectors produced by interpreting the
+reference's own serialized graph (tests/golden/make_golden.py)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from deepmod_amd import synth, tfbundle
+from oracle import oracle_np
+
+FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "bilstm_*.npz")))
+
+
+def test_fixtures_present():
+    assert len(FIXTURES) == 10  # 5 shipped BiLSTM models x 2 weight regimes
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[7:-4] for p in FIXTURES])
+def test_oracle_matches_interpreted_reference_graph(path):
+    g = np.load(path)
+    w = synth.synthetic_weights(int(g["seed_w"]), float(g["scale"]))
+    wsum = sum(np.abs(v.astype(np.float64)).sum() for v in w.values())
+    assert abs(wsum - float(g["weight_abs_sum"])) < 1e-6 * wsum, "synthetic weight generator drifted"
+    assert int(g["matmuls"]) == 67  # 11 live steps x 3 layers x 2 dirs + head
+    prob_c, cls_c = oracle_np.predict_windows_c(w, g["X"])
+    assert np.abs(prob_c - g["prob"]).max() <= 5e-6
+    assert np.array_equal(cls_c, g["cls"])
+    if path.endswith("conmodC_P100wd21_f7ne1u0_4_s4.npz"):
+        prob_n, cls_n, _ = oracle_np.predict_windows_np(w, g["X"])
+        assert np.abs(prob_n - g["prob"]).max() <= 1e-6
+        assert np.array_equal(cls_n, g["cls"])
+
+
+def test_oracle_thread_count_invariant():
+    w = synth.synthetic_weights(3, 1.0)
+    x = synth.synthetic_windows(97, seed=9)
+    p1, c1 = oracle_np.predict_windows_c(w, x, nthreads=1)
+    p4, c4 = oracle_np.predict_windows_c(w, x, nthreads=4)
+    assert np.array_equal(p1, p4) and np.array_equal(c1, c4)
+
+
+def test_oracle_empty():
+    w = synth.synthetic_weights(3, 1.0)
+    p, c = oracle_np.predict_windows_c(w, np.zeros((0, 21, 7), np.float32))
+    assert p.shape == (0, 2) and c.shape == (0,)
+
+
+def test_index_tables_match_synthetic_layout():
+    """The real checkpoints' .index tables (recorded as data) agree with the layout the synthetic
+    checkpoint writer reproduces."""
+    tables = json.load(open(os.path.join(GOLDEN, "index_tables.json")))
+    assert len(tables) == 5
+    for model, t in tables.items():
+        ent = t["entries"]
+        for name, off in synth.REAL_LAYOUT.items():
+            assert ent[name]["offset"] == off, (model, name)
+        for name, shape in synth.variable_shapes():
+            assert tuple(ent[name]["shape"]) == shape
+        assert max(e["offset"] + e["size"] for e in ent.values()) == synth.REAL_DATA_SIZE
+
+
+def test_bundle_roundtrip_real_layout(tmp_path):
+    prefix = str(tmp_path / "mod_train_synth")
+    w = synth.write_synthetic_checkpoint(prefix, seed=5, scale=1.0)
+    assert os.path.getsize(tfbundle.data_path(prefix)) == synth.REAL_DATA_SIZE
+    back = tfbundle.load_bundle(prefix, verify_crc=True)
+    assert set(back) == set(w)
+    for k in w:
+        assert np.array_equal(back[k], w[k])
+    assert tfbundle.latest_checkpoint(str(tmp_path)) == prefix
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/train_deepmod"), reason="reference tree not present")
+def test_reader_on_real_index_files():
+    import glob as g
+    paths = sorted(g.glob("/root/reference/train_deepmod/rnn_*/*.index"))
+    assert len(paths) == 5
+    tables = json.load(open(os.path.join(GOLDEN, "index_tables.json")))
+    for p in paths:
+        ent = tfbundle.read_index(p)
+        rec = tables[os.path.basename(os.path.dirname(p))]["entries"]
+        assert {n: (list(e.shape), e.offset, e.size, e.crc32c) for n, e in ent.items()} == \
+               {n: (v["shape"], v["offset"], v["size"], v["crc32c"]) for n, v in rec.items()}
+    # the one complete checkpoint in the tree (cluster MLP): CRCs verify
+    t = tfbundle.load_bundle("/root/reference/train_deepmod/na12878_cluster_train_mod-keep_prob0.7-nb25-chr1/Cg.cov5.nb25",
+                             verify_crc=True)
+    assert t["W_1"].shape == (14, 100)

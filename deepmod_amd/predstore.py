@@ -1,0 +1,135 @@
+"""On-disk containers used on either side of the hot path.
+
+* feature container  `<name>.dmfeat.npz`: for each read exactly what the reference hands to
+  mPredict1 (myDetect.py:715): `mfeatures float64[N+200,10]` (get_Feature, :839-903),
+  `base_map_info` (:660), the clips, and the basecalled base of every event.  Stands in for the
+  FAST5 + aligner front end, which is out of scope this round (no h5py / minimap2 here).
+* prediction store   `rnn.pred.detail.npz.<batchid>`: per-read `predetail` table + the attributes the
+  reference stores in HDF5 (`pred/<key>/predetail`, myDetect.py:716-760).  h5py is not available in
+  this image, so the same fields are kept in an .npz; the index-file lines are byte-compatible.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, List
+
+import numpy as np
+
+CONTAINER_SUFFIX = '.dmfeat.npz'
+EVENT_DTYPE = [('mean', '<f4'), ('stdv', '<f4'), ('start', np.uint64), ('length', np.uint64), ('model_state', 'U5')]
+BMI_DTYPE = [('refbase', 'U1'), ('readbase', 'U1'), ('refbasei', np.uint64), ('readbasei', np.uint64), ('mod_pred', int)]
+
+
+def make_base_map_info(refbase, readbase, refbasei, readbasei=None, mod_pred=None) -> np.ndarray:
+    n = len(refbase)
+    bmi = np.zeros(n, dtype=BMI_DTYPE)
+    bmi['refbase'] = refbase
+    bmi['readbase'] = readbase
+    bmi['refbasei'] = refbasei
+    bmi['readbasei'] = readbasei if readbasei is not None else 0
+    bmi['mod_pred'] = mod_pred if mod_pred is not None else 0
+    return bmi
+
+
+def events_from_bases(bases, mean=None, stdv=None, length=None) -> np.ndarray:
+    ev = np.zeros(len(bases), dtype=EVENT_DTYPE)
+    ev['model_state'] = np.char.add(np.char.add('NN', np.asarray(bases, dtype='U1')), 'NN')
+    if mean is not None:
+        ev['mean'] = mean
+    if stdv is not None:
+        ev['stdv'] = stdv
+    if length is not None:
+        ev['length'] = length
+    return ev
+
+
+def save_feature_container(path: str, reads: List[Dict]) -> None:
+    arrays = {}
+    metas = []
+    for i, rd in enumerate(reads):
+        bmi = rd['base_map_info']
+        arrays['r%d_mfeatures' % i] = np.asarray(rd['mfeatures'], dtype=np.float64)
+        arrays['r%d_refbase' % i] = bmi['refbase'].astype('U1')
+        arrays['r%d_readbase' % i] = bmi['readbase'].astype('U1')
+        arrays['r%d_refbasei' % i] = bmi['refbasei'].astype(np.uint64)
+        arrays['r%d_readbasei' % i] = bmi['readbasei'].astype(np.uint64)
+        arrays['r%d_evbase' % i] = np.array([s[2] for s in rd['events']['model_state']], dtype='U1')
+        metas.append({k: rd[k] for k in ('readk', 'chr', 'strand', 'mapped_start', 'start_clip', 'end_clip')})
+    arrays['meta'] = np.array(json.dumps(metas))
+    if not path.endswith(CONTAINER_SUFFIX):
+        raise ValueError('feature containers must end with ' + CONTAINER_SUFFIX)
+    with open(path, 'wb') as fh:
+        np.savez_compressed(fh, **arrays)
+
+
+def load_feature_container(path: str) -> List[Dict]:
+    z = np.load(path, allow_pickle=False)
+    metas = json.loads(str(z['meta']))
+    reads = []
+    for i, m in enumerate(metas):
+        rd = dict(m)
+        rd['mfeatures'] = z['r%d_mfeatures' % i]
+        rd['base_map_info'] = make_base_map_info(z['r%d_refbase' % i], z['r%d_readbase' % i], z['r%d_refbasei' % i],
+                                                 z['r%d_readbasei' % i])
+        rd['events'] = events_from_bases(z['r%d_evbase' % i])
+        reads.append(rd)
+    return reads
+
+
+class PredWriter:
+    """Collects the per-read prediction tables of one worker batch (file name and index-line fields
+    follow myDetect.py:716-718)."""
+
+    def __init__(self, ctfolder: str, batchid: int):
+        self.path = os.path.join(ctfolder.rstrip('/\\'), 'rnn.pred.detail.npz.' + str(batchid))
+        self.arrays = {}
+        self.attrs = {}
+        self.n = 0
+
+    def relpath(self, moptions) -> str:
+        return os.path.relpath(self.path, moptions['outFolder'] + moptions['FileID'])
+
+    def add(self, rd, bmi, pred_mod_num, src_file, moptions) -> str:
+        key = 'pred_' + str(self.n)
+        self.n += 1
+        for f in ('refbase', 'readbase'):
+            self.arrays[key + '/' + f] = bmi[f].astype('S1')
+        self.arrays[key + '/refbasei'] = bmi['refbasei'].astype(np.uint64)
+        self.arrays[key + '/readbasei'] = bmi['readbasei'].astype(np.uint64)
+        self.arrays[key + '/mod_pred'] = bmi['mod_pred'].astype(np.int64)
+        fwd = rd['strand'] == '+'
+        nins = int((bmi['refbase'] == '-').sum())
+        ndel = int((bmi['readbase'] == '-').sum())
+        nmis = int(((bmi['refbase'] != bmi['readbase']) & (bmi['refbase'] != '-') & (bmi['readbase'] != '-')).sum())
+        self.attrs[key] = {
+            'mapped_chr': rd['chr'], 'mapped_strand': rd['strand'],
+            'mapped_start': int(bmi['refbasei'][0] if fwd else bmi['refbasei'][-1]),
+            'mapped_end': int(bmi['refbasei'][-1] if fwd else bmi['refbasei'][0]),
+            'clipped_bases_start': int(rd['start_clip']), 'clipped_bases_end': int(rd['end_clip']),
+            'num_insertions': nins, 'num_deletions': ndel, 'num_mismatches': nmis,
+            'num_matches': int(len(bmi) - nmis - nins - ndel),
+            'pred_mod_num': int(pred_mod_num), 'f5file': src_file, 'readk': rd['readk']}
+        return key
+
+    def close(self):
+        if self.n == 0:
+            return
+        self.arrays['attrs'] = np.array(json.dumps(self.attrs))
+        os.makedirs(os.path.dirname(self.path), exist_ok=True)
+        with open(self.path, 'wb') as fh:
+            np.savez_compressed(fh, **self.arrays)
+
+
+_cache = {'path': None, 'z': None, 'attrs': None}
+
+
+def read_pred(path: str, key: str):
+    """-> (m_pred, mapped_chr, mapped_strand) with the dtype the reference builds at myDetect.py:1022."""
+    if _cache['path'] != path:
+        z = np.load(path, allow_pickle=False)
+        _cache.update(path=path, z=z, attrs=json.loads(str(z['attrs'])))
+    z, attrs = _cache['z'], _cache['attrs']
+    m_pred = make_base_map_info(z[key + '/refbase'].astype('U1'), z[key + '/readbase'].astype('U1'),
+                                z[key + '/refbasei'], z[key + '/readbasei'], z[key + '/mod_pred'])
+    return m_pred, attrs[key]['mapped_chr'], attrs[key]['mapped_strand']

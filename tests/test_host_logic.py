@@ -1,0 +1,130 @@
+"""CPU: host-side logic (windowing, batching, class->base scatter, flags, BED bytes) against golden
+vectors recorded from the reference's own Python, and against the loop-level oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from deepmod_amd import detect, predstore, summary
+from oracle import detect_oracle, oracle_np
+
+
+def fake_rule(x):
+    x = np.asarray(x)
+    return ((x[:, 10, 1] > 0.5) & (x[:, 10, 4] > 0.0)).astype(np.int64)
+
+
+class FakeSession:
+    """Any session-like object: mPredict1 must drive it exactly as the reference does."""
+    def __init__(self):
+        self.batches, self.inits, self.dtypes = [], 0, []
+
+    def run(self, fetches, feed_dict=None):
+        if feed_dict is None:
+            self.inits += 1
+            return None
+        assert fetches == ['mfpred']
+        x, y = feed_dict['X'], feed_dict['Y']
+        assert y.shape == (len(x), 2) and y.dtype.kind == 'i' and not y.any()
+        self.batches.append(len(x))
+        self.dtypes.append(x.dtype)
+        return [fake_rule(x)]
+
+
+G = np.load(os.path.join(GOLDEN, 'host_mpredict1.npz'))
+
+
+def _case(ci):
+    ev = predstore.events_from_bases([s[2] for s in G['c%d_model_state' % ci]])
+    assert (ev['model_state'] == G['c%d_model_state' % ci]).all()
+    bmi = predstore.make_base_map_info(G['c%d_bmi_refbase' % ci], G['c%d_bmi_readbase' % ci],
+                                       G['c%d_bmi_refbasei' % ci], G['c%d_bmi_readbasei' % ci])
+    sc, ec = [int(v) for v in G['c%d_clips' % ci]]
+    return ev, bmi, sc, ec
+
+
+@pytest.mark.parametrize('ci', range(int(G['n_cases'])))
+def test_mpredict1_matches_reference_run(ci):
+    ev, bmi, sc, ec = _case(ci)
+    sess = FakeSession()
+    sp_options = {'rnn': (sess, 'X', 'Y', 'init_l', 'mfpred')}
+    sp_param = {'f5data': {'r': (None, ev, None, 'f')}}
+    pred = detect.mPredict1({'windowsize': 21}, sp_options, sp_param, G['c%d_mfeatures' % ci].copy(), bmi, 'r', sc, ec)
+    assert sess.inits == 1
+    assert sess.batches == G['c%d_batches' % ci].tolist()           # the ~512 split rule (myDetect.py:808-812)
+    assert all(dt == np.float64 for dt in sess.dtypes)                # float64 feed, as the reference
+    assert pred == int(G['c%d_pred_mod_num' % ci])
+    assert np.array_equal(bmi['mod_pred'].astype(np.int64), G['c%d_mod_pred' % ci])
+
+
+@pytest.mark.parametrize('ci', [0, 4, 6])
+def test_loop_oracle_matches_reference_run(ci):
+    ev, bmi, sc, ec = _case(ci)
+    ev_bases = [s[2] for s in G['c%d_model_state' % ci]]
+    batches, pred, mod_pred = detect_oracle.mpredict1_oracle(G['c%d_mfeatures' % ci], list(bmi['readbase']), ev_bases,
+                                                            sc, ec, fake_rule)
+    assert batches == G['c%d_batches' % ci].tolist()
+    assert pred == int(G['c%d_pred_mod_num' % ci])
+    assert np.array_equal(mod_pred, G['c%d_mod_pred' % ci])
+
+
+def test_mpredict1_zero_aligned_events_returns_zero():
+    ev = predstore.events_from_bases(list('ACGT'))
+    bmi = predstore.make_base_map_info(['A'], ['A'], [1])
+    assert detect.mPredict1({'windowsize': 21}, {'rnn': (FakeSession(), 'X', 'Y', 'i', 'mfpred')},
+                            {'f5data': {'r': (None, ev, None, 'f')}}, np.zeros((200, 10)), bmi, 'r', 2, 2) == 0
+
+
+SUMS = json.load(open(os.path.join(GOLDEN, 'host_sum_handler.json')))
+
+
+def _tables(case):
+    return [predstore.make_base_map_info(list(r['refbase']), list(r['readbase']), r['refbasei'], None, r['mod_pred'])
+            for r in case['reads']]
+
+
+@pytest.mark.parametrize('case', SUMS, ids=[c['strand'] for c in SUMS])
+def test_bed_bytes_match_reference_sum_handler(case):
+    """flags -> counters (oracle C restatement of the accumulation) -> bed_lines == the reference's bytes."""
+    length = 1 + max(max(r['refbasei']) for r in case['reads'])
+    touch = np.zeros(length, np.int32); cov = np.zeros(length, np.int32); mod = np.zeros(length, np.int32)
+    for m_pred in _tables(case):
+        fl = detect.base_flags(m_pred, case['Base'])
+        oracle_np.summary_add_c(touch, cov, mod, m_pred['refbasei'].astype(np.int64), fl)
+    bed = summary.bed_lines(case['chr'], case['strand'], case['Base'], touch, cov, mod)
+    assert bed == case['bed'].encode('ascii')
+    assert b' 1000 ' in bed and b' 1203 ' in bed          # column-5 cap vs real coverage
+    assert bed.startswith(b'chrS 40 41 C 0 ')             # deletion-only position is emitted with cov 0
+    # loop-level oracle agrees as well
+    assert detect_oracle.sum_handler_oracle(case['chr'], case['strand'], case['Base'], case['reads']) == bed
+
+
+def test_feature_container_roundtrip(tmp_path):
+    ev, bmi, sc, ec = _case(0)
+    rd = {'readk': 'read0', 'chr': 'chrS', 'strand': '+', 'mapped_start': 1000, 'start_clip': sc, 'end_clip': ec,
+          'mfeatures': G['c0_mfeatures'], 'base_map_info': bmi, 'events': ev}
+    path = str(tmp_path / ('a' + predstore.CONTAINER_SUFFIX))
+    predstore.save_feature_container(path, [rd, rd])
+    back = predstore.load_feature_container(path)
+    assert len(back) == 2
+    assert np.array_equal(back[1]['mfeatures'], rd['mfeatures'])
+    for f in ('refbase', 'readbase', 'refbasei', 'readbasei'):
+        assert np.array_equal(back[0]['base_map_info'][f], bmi[f])
+    assert (back[0]['events']['model_state'] == ev['model_state']).all()
+
+
+def test_pred_store_roundtrip(tmp_path):
+    ev, bmi, sc, ec = _case(1)
+    bmi['mod_pred'][::7] = 1
+    rd = {'readk': 'read0', 'chr': 'chrS', 'strand': '-', 'mapped_start': 1000, 'start_clip': sc, 'end_clip': ec}
+    mo = {'outFolder': str(tmp_path) + '/', 'FileID': 'mod'}
+    w = predstore.PredWriter(str(tmp_path / 'mod' / '0'), 3)
+    key = w.add(rd, bmi, 17, 'x.dmfeat.npz', mo)
+    w.close()
+    assert w.relpath(mo) == '0/rnn.pred.detail.npz.3'
+    m_pred, c, s = predstore.read_pred(w.path, key)
+    assert (c, s) == ('chrS', '-')
+    for f in ('refbase', 'readbase', 'refbasei', 'mod_pred'):
+        assert np.array_equal(m_pred[f], bmi[f])

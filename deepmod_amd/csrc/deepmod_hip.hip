@@ -90,8 +90,8 @@ Packed pack_weights(const float* flat) {
                     }
                     for (int t = 0; t < NT; ++t) {
                         const float v = krow < 0 ? 0.0f : kern[size_t(krow) * 400 + gate_col(t, c)];
-                        if (t < 24) dst[((t >> 2) * 64 + lane) * 4 + (t & 3)] = v;
-                        else dst[6 * 256 + lane] = v;
+                        if (t < 24) dst[((t >> 2) * 64 + lane) * 4 + (t & 3)] = v;   // [tile quad][lane][4]
+                        else dst[6 * 256 + lane] = v;                                // tile 24: [lane]
                     }
                 }
             }
@@ -327,7 +327,7 @@ int model_init(dm_model* m, const float* weights) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(DM_EDEVICE, "device %d is %s; this library is built for gfx950 only", m->device, prop.gcnArchName);
     m->num_cu = prop.multiProcessorCount;
-    m->grid_cap = m->num_cu;  // 120 KB of LDS per workgroup -> one resident workgroup per CU
+    m->grid_cap = m->num_cu;  // 120 KB of LDS per workgroup -> one resident (persistent) workgroup per CU
     HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     Packed P = pack_weights(weights);
     m->bout[0] = P.bout[0];

@@ -1,0 +1,70 @@
+"""Dev tool: build ablated variants of the BiLSTM kernel (timing only - results are wrong by
+construction) and time them on the GPU box.
+
+    python tools/ablate.py build            # here (cross-compile)
+    python tools/ablate.py run              # on the GPU box (via gpurun)
+"""
+import os, subprocess, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ABL = os.path.join(ROOT, "tools", "_abl")
+VARIANTS = {
+    "base": [],
+    "nopeel": ["-DDM_ABL_NOPEEL"],
+    "noepi": ["-DDM_ABL_NOEPI"],
+    "noseq": ["-DDM_ABL_NOSEQ"],
+    "nobar": ["-DDM_ABL_NOBAR"],
+    "nodma": ["-DDM_ABL_NODMA"],
+    "mfma_only": ["-DDM_ABL_NOEPI", "-DDM_ABL_NOBAR", "-DDM_ABL_NODMA", "-DDM_ABL_NOSEQ"],
+}
+EXTRA = sys.argv[3:] if len(sys.argv) > 3 else []
+
+
+def build(names):
+    os.makedirs(ABL, exist_ok=True)
+    src = os.path.join(ROOT, "deepmod_amd", "csrc", "deepmod_hip.hip")
+    for name in names:
+        out = os.path.join(ABL, "lib_%s.so" % name)
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", out, src,
+               "-ldl"] + VARIANTS[name]
+        subprocess.check_call(cmd, cwd=os.path.dirname(src))
+        print("built", out)
+
+
+def run(names, n=65536, reps=6):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from deepmod_amd import _lib, model, synth
+    res = {}
+    x = synth.synthetic_windows(n, seed=1)
+    w = synth.synthetic_weights(7, 1.0)
+    for name in names:
+        path = os.path.join(ABL, "lib_%s.so" % name)
+        if not os.path.exists(path):
+            continue
+        _lib._LIB = None
+        _lib.LIB_PATH = path
+        m = model.BiLSTMModel(w, 0)
+        m.set_option(_lib.DM_OPT_PROFILE, 1)
+        dx = model.DeviceArray.from_host(x, 0)
+        dc = model.DeviceArray((n,), np.uint8, 0)
+        m.predict_windows(dx, cls=dc, want_prob=False)
+        m.profile_reset()
+        for _ in range(reps):
+            m.predict_windows(dx, cls=dc, want_prob=False)
+        ms, launches, _ = m.profile_get()
+        res[name] = ms / launches
+        print("%-14s %.3f ms/launch  %.3g windows/s  %.1f%% of fp32 MFMA peak" %
+              (name, res[name], n / res[name] * 1e3, n * 8.924e6 / (res[name] * 1e-3) / 157.3e12 * 100), flush=True)
+        m.close(); dx.free(); dc.free()
+    return res
+
+
+if __name__ == "__main__":
+    names = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] != "all" else list(VARIANTS)
+    if sys.argv[1] == "build":
+        build(names)
+    elif sys.argv[1] == "run1":
+        run(names)
+    else:  # one process per variant: same-named kernel symbols would interpose across dlopen()ed variants
+        for nm in names:
+            subprocess.call([sys.executable, os.path.abspath(__file__), "run1", nm])

@@ -31,23 +31,57 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f
 CONTIG_LEN = 4_641_652        # E. coli K-12 sized contig for the synthetic summary
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (a container
+    that reports 256 logical CPUs but is throttled to a few would otherwise oversubscribe OpenMP)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(weights, x_sample_src):
-    """Oracle (C restatement, OpenMP) on the host cores of this box, bounded to ~10-20 s."""
+    """Oracle (C restatement, OpenMP) on the host cores of this box, bounded to ~12 s of CPU work."""
     from oracle import oracle_np
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     oracle_np.build_c_oracle()
     probe = x_sample_src[:max(256, 32 * cores)]
+    oracle_np.predict_windows_c(weights, probe, nthreads=cores)          # warm up threads / caches
     t0 = time.perf_counter()
     oracle_np.predict_windows_c(weights, probe, nthreads=cores)
-    dt = time.perf_counter() - t0
-    rate = len(probe) / max(dt, 1e-6)
-    n = int(min(len(x_sample_src), max(len(probe), rate * 12.0)))
+    rate = len(probe) / max(time.perf_counter() - t0, 1e-6)
+    reps = int(max(1, min(64, rate * 12.0 / len(x_sample_src))))           # whole passes over batch 0
     t0 = time.perf_counter()
-    oracle_np.predict_windows_c(weights, x_sample_src[:n], nthreads=cores)
+    for _ in range(reps):
+        oracle_np.predict_windows_c(weights, x_sample_src, nthreads=cores)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "base-positions/s", "cores": cores, "kind": "port",
-            "sample": "first %d windows of batch 0, oracle/deepmod_oracle.c (fp32 restatement of the TF graph, "
-                      "not TensorFlow), %d OpenMP threads, %.1f s" % (n, cores, dt)}
+    n = reps * len(x_sample_src)
+    return {"value": n / dt, "unit": "base-positions/s", "cores": cores, "logical_cpus": os.cpu_count(), "kind": "port",
+            "sample": "%d pass(es) over the %d windows of batch 0 (%d windows), oracle/deepmod_oracle.c = fp32 C "
+                      "restatement of the TF graph with libm expf/tanhf (NOT TensorFlow/Eigen), %d OpenMP threads, %.1f s"
+                      % (reps, len(x_sample_src), n, cores, dt)}
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/<round>/pmc_summary.json: FETCH_SIZE and WRITE_SIZE in KB, separate --pmc passes;
+    gfx950 correction: FETCH_SIZE x 2 for wide coalesced reads, MI355X_MICROARCH.md HBM section)."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+    try:
+        pmc = json.load(open(path))
+        fetch = pmc["FETCH_SIZE"]["mean_per_launch"] * 1024.0
+        write = pmc["WRITE_SIZE"]["mean_per_launch"] * 1024.0
+        return {"bytes": 2.0 * fetch + write, "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
+                "source": os.path.relpath(path, ROOT), "windows_per_launch": pmc.get("windows_per_launch", BATCH)}
+    except Exception:
+        return None
 
 
 def main():
@@ -66,7 +100,8 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    dist_mode = world > 1 or os.environ.get("DM_BENCH_FORCE_DIST") == "1"   # 1-rank dry run of the N > 1 path
+    if dist_mode:
         import torch  # torch first: its HIP/RCCL runtime is the one the process group uses
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -77,7 +112,7 @@ def main():
     lib = _lib.load()
     if lib.dm_device_count() < 1:
         raise SystemExit("bench.py: no gfx950 device visible; there is no CPU fallback")
-    device = local_rank if world > 1 else 0
+    device = local_rank if dist_mode else 0
 
     weights = synth.synthetic_weights(seed=7, scale=1.0)
     m = model.BiLSTMModel(weights, device=device)
@@ -133,7 +168,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-    if world > 1:
+    if dist_mode:
         summ.all_reduce_torch(dist)
     sync_all()
     if dist is not None:
@@ -152,6 +187,7 @@ def main():
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = (kwindows / max(launches, 1)) * FLOP_PER_WINDOW / avg_launch_s / 1e12
         touch, cov, mod = summ.fetch()
+        traffic = measured_traffic()
         out = {
             "metric": "base-positions/sec (whole node), E. coli 5mC wd21/f7 BiLSTM",
             "value": value, "unit": "base-positions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -160,10 +196,11 @@ def main():
             "config": {"workload": "configs[1]: rnn_conmodC_P100wd21_f7ne1u0_4 geometry (3x100 BiLSTM, wd21, f7), "
                                    "synthetic weights (real .data shards absent), %d windows/step resident in HBM, "
                                    "%d distinct batches (1,048,576 windows)" % (BATCH, n_batches),
-                       "batch": BATCH, "windows_total": total_windows, "parallelism": "window-sharded x%d" % world,
+                       "batch": BATCH, "windows_total": total_windows, "parallelism": "window-sharded x%d" % world, "forced_dist_dry_run": bool(dist_mode and world == 1),
                        "precision": "f32 MFMA (exact)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": (traffic or {}).get("bytes"),
+                         "traffic_detail": traffic, "algorithmic_bytes": 596 * BATCH,
                          "kernel": "lstm32::bilstm_f32_kernel", "avg_launch_ms": avg_launch_s * 1e3,
                          "launches": launches, "flop_per_window": FLOP_PER_WINDOW,
                          "peak_note": "v_mfma_f32_16x16x4_f32 dense fp32, 157.3 TF"},

@@ -56,26 +56,38 @@ int64_t dmo_weight_count(void) {
 
 static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-/* one LSTM cell step for one window: inp[kin], h[100], c[100] updated in place */
-static void cell_step(const float* kernel, const float* bias, const float* inp, int kin,
-                      float* h, float* c, float* g) {
-    for (int n = 0; n < NG; ++n) g[n] = 0.0f;
+/* one LSTM cell step (BasicLSTMCell.call) for a block of WB windows: inp[w][kin], h[w][100], c[w][100] updated
+ * in place; each kernel row is reused across the block from L1; k-ascending summation per output element */
+#define WB 8
+static void cell_step_block(const float* kernel, const float* bias, const float* const* inp, int kin,
+                            float (*h)[HID], float (*c)[HID], float (*g)[NG], int nb) {
+    for (int w = 0; w < nb; ++w)
+        for (int n = 0; n < NG; ++n) g[w][n] = 0.0f;
     for (int k = 0; k < kin; ++k) {
-        const float a = inp[k];
-        const float* w = kernel + (int64_t)k * NG;
-        for (int n = 0; n < NG; ++n) g[n] += a * w[n];
+        const float* wr = kernel + (int64_t)k * NG;
+        for (int w = 0; w < nb; ++w) {
+            const float a = inp[w][k];
+            float* gw = g[w];
+            for (int n = 0; n < NG; ++n) gw[n] += a * wr[n];
+        }
     }
     for (int k = 0; k < HID; ++k) {
-        const float a = h[k];
-        const float* w = kernel + (int64_t)(kin + k) * NG;
-        for (int n = 0; n < NG; ++n) g[n] += a * w[n];
+        const float* wr = kernel + (int64_t)(kin + k) * NG;
+        for (int w = 0; w < nb; ++w) {
+            const float a = h[w][k];
+            float* gw = g[w];
+            for (int n = 0; n < NG; ++n) gw[n] += a * wr[n];
+        }
     }
-    for (int n = 0; n < NG; ++n) g[n] += bias[n]; /* BiasAdd after MatMul, as in the graph */
-    for (int u = 0; u < HID; ++u) {
-        const float gi = g[u], gj = g[HID + u], gf = g[2 * HID + u], go = g[3 * HID + u];
-        const float cn = c[u] * sigmoidf_(gf + 1.0f) + sigmoidf_(gi) * tanhf(gj);
-        c[u] = cn;
-        h[u] = tanhf(cn) * sigmoidf_(go);
+    for (int w = 0; w < nb; ++w) {
+        float* gw = g[w];
+        for (int n = 0; n < NG; ++n) gw[n] += bias[n];
+        for (int u = 0; u < HID; ++u) {
+            const float gi = gw[u], gj = gw[HID + u], gf = gw[2 * HID + u], go = gw[3 * HID + u];
+            const float cn = c[w][u] * sigmoidf_(gf + 1.0f) + sigmoidf_(gi) * tanhf(gj);
+            c[w][u] = cn;
+            h[w][u] = tanhf(cn) * sigmoidf_(go);
+        }
     }
 }
 
@@ -101,43 +113,47 @@ int dmo_predict_windows(const float* weights, const float* x, int64_t n, float* 
     (void)nthreads;
 #endif
 #pragma omp parallel for schedule(static)
-    for (int64_t w = 0; w < n; ++w) {
-        float h[2][3][HID], c[2][3][HID], g[NG];
+    for (int64_t w0 = 0; w0 < n; w0 += WB) {
+        const int nb = (int)((n - w0) < WB ? (n - w0) : WB);
+        float h[2][3][WB][HID], c[2][3][WB][HID], g[WB][NG];
         memset(h, 0, sizeof h); /* MultiRNNCellZeroState */
         memset(c, 0, sizeof c);
-        const float* xw = x + w * WIN * NFEAT;
         for (int d = 0; d < 2; ++d) {
             for (int s = 0; s < LIVE; ++s) {
                 const int row = d == 0 ? s : (WIN - 1 - s);
-                const float* inp = xw + row * NFEAT;
+                const float* inp[WB];
+                for (int w = 0; w < nb; ++w) inp[w] = x + (w0 + w) * WIN * NFEAT + row * NFEAT;
                 int kin = NFEAT;
                 for (int l = 0; l < 3; ++l) {
-                    cell_step(kern[d][l], bias[d][l], inp, kin, h[d][l], c[d][l], g);
-                    inp = h[d][l];
+                    cell_step_block(kern[d][l], bias[d][l], inp, kin, h[d][l], c[d][l], g, nb);
+                    for (int w = 0; w < nb; ++w) inp[w] = h[d][l][w];
                     kin = HID;
                 }
             }
         }
-        /* concat_10 = [fw h2, bw h2]; logits = . @ W + b */
-        float lg[2] = {0.0f, 0.0f};
-        for (int d = 0; d < 2; ++d)
-            for (int u = 0; u < HID; ++u) {
-                lg[0] += h[d][2][u] * wout[(d * HID + u) * 2 + 0];
-                lg[1] += h[d][2][u] * wout[(d * HID + u) * 2 + 1];
+        for (int wi = 0; wi < nb; ++wi) {
+            const int64_t w = w0 + wi;
+            /* concat_10 = [fw h2, bw h2]; logits = . @ W + b */
+            float lg[2] = {0.0f, 0.0f};
+            for (int d = 0; d < 2; ++d)
+                for (int u = 0; u < HID; ++u) {
+                    lg[0] += h[d][2][wi][u] * wout[(d * HID + u) * 2 + 0];
+                    lg[1] += h[d][2][wi][u] * wout[(d * HID + u) * 2 + 1];
+                }
+            lg[0] += bout[0];
+            lg[1] += bout[1];
+            const float m = lg[0] > lg[1] ? lg[0] : lg[1];
+            const float e0 = expf(lg[0] - m), e1 = expf(lg[1] - m);
+            const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+            if (prob) {
+                prob[2 * w] = p0;
+                prob[2 * w + 1] = p1;
             }
-        lg[0] += bout[0];
-        lg[1] += bout[1];
-        const float m = lg[0] > lg[1] ? lg[0] : lg[1];
-        const float e0 = expf(lg[0] - m), e1 = expf(lg[1] - m);
-        const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
-        if (prob) {
-            prob[2 * w] = p0;
-            prob[2 * w + 1] = p1;
-        }
-        if (cls) cls[w] = p1 > p0 ? 1 : 0; /* tf.argmax: ties -> index 0 */
-        if (hcat) {
-            memcpy(hcat + w * 2 * HID, h[0][2], HID * sizeof(float));
-            memcpy(hcat + w * 2 * HID + HID, h[1][2], HID * sizeof(float));
+            if (cls) cls[w] = p1 > p0 ? 1 : 0; /* tf.argmax: ties -> index 0 */
+            if (hcat) {
+                memcpy(hcat + w * 2 * HID, h[0][2][wi], HID * sizeof(float));
+                memcpy(hcat + w * 2 * HID + HID, h[1][2][wi], HID * sizeof(float));
+            }
         }
     }
     return 0;

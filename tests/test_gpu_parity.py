@@ -153,3 +153,23 @@ def test_session_adapter_matches_reference_call_forms(models, tmp_path, gpu_devi
     near = np.abs(ref_prob[:, 1] - 0.5) < TOL
     assert np.array_equal(out[~near], ref_cls[~near])
     sess.close()
+
+
+def test_bench_distributed_path_single_rank(gpu_device):
+    """The N > 1 code path of bench.py (torch.distributed nccl init, per-rank device, the counter
+    all-reduce through the aliased torch tensor, MAX-reduced timing) exercised with one rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, DM_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["config"]["forced_dist_dry_run"] is True
+    assert out["value"] > 1e6 and out["summary_check"]["touch"] > 0

@@ -1,0 +1,24 @@
+"""Dev tool: condense gpurun_out/prof_<tag>/ (from tools/profile_round.sh) into profiles/<round>/."""
+import collections, csv, glob, json, os, shutil, sys
+tag, dest = sys.argv[1], sys.argv[2]
+src = os.path.join("gpurun_out", "prof_" + tag)
+os.makedirs(dest, exist_ok=True)
+stats = glob.glob(src + "/kt/*/*_kernel_stats.csv")
+if stats:
+    shutil.copy(stats[0], os.path.join(dest, "kernel_stats.csv"))
+out = {}
+for d in sorted(glob.glob(src + "/pmc_*")):
+    files = glob.glob(d + "/*/*_counter_collection.csv")
+    if not files:
+        continue
+    acc = collections.defaultdict(list)
+    dur = []
+    for r in csv.DictReader(open(files[0])):
+        if "bilstm" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k, v in acc.items():
+        out[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v), "mean_kernel_ns_in_this_pass": sum(dur) / len(dur)}
+out["windows_per_launch"] = 65536
+json.dump(out, open(os.path.join(dest, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps({k: (v["mean_per_launch"] if isinstance(v, dict) else v) for k, v in out.items()}, indent=1))

@@ -118,27 +118,56 @@ Packed pack_weights(const float* flat) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// summary kernel: dense int32 counters, one atomic per qualifying base
+// summary kernel: dense int32 counters with a wavefront-level pre-reduction.
+// Bases arrive read by read, so a wave mostly sees 64 consecutive distinct positions (one atomic per
+// counter per base), but deep pile-ups (amplicons, the cov > 1000 case of the BED format) put long
+// runs of the SAME position next to each other: adjacent lanes holding the same position form a run,
+// the run's head lane counts the run's flags with ballot + popcount and issues ONE atomic per
+// counter for the whole run.  Integer adds commute, so the result is bit-identical either way.
+// HBM-bound in principle (10 B per base in); at today's batch sizes it is launch-latency bound.
 // ---------------------------------------------------------------------------------------------
 __global__ void summary_add_kernel(int* __restrict__ touch, int* __restrict__ cov, int* __restrict__ mod,
                                    const long long length, const long long* __restrict__ pos,
                                    const unsigned char* __restrict__ flags,
                                    const unsigned char* __restrict__ cls, const long long n,
                                    int* __restrict__ oob) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x) {
-        unsigned f = flags[i];
-        if (cls) f = (f & 3u) | (cls[i] == 1 ? 4u : 0u);
-        if (!(f & 1u)) continue;
-        const long long q = pos[i];
-        if (q < 0 || q >= length) {
-            atomicAdd(oob, 1);
-            continue;
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    // whole waves iterate together so that ballots see all 64 lanes
+    for (long long base = blockIdx.x * (long long)blockDim.x + (threadIdx.x & ~63); base < n; base += stride) {
+        const long long i = base + lane;
+        unsigned f = 0;
+        long long q = -1 - lane;                      // inactive lanes get distinct keys: never merged
+        if (i < n) {
+            f = flags[i];
+            if (cls) f = (f & 3u) | (cls[i] == 1 ? 4u : 0u);
+            if (f & 1u) {
+                q = pos[i];
+                if (q < 0 || q >= length) {
+                    atomicAdd(oob, 1);
+                    f = 0;
+                    q = -1 - lane;
+                }
+            } else {
+                f = 0;
+            }
         }
-        atomicAdd(touch + q, 1);
-        if (f & 2u) {
-            atomicAdd(cov + q, 1);
-            if (f & 4u) atomicAdd(mod + q, 1);
+        const long long qprev = __shfl_up(q, 1, 64);
+        const bool head = lane == 0 || q != qprev;
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long m_touch = __ballot((f & 1u) != 0);
+        const unsigned long long m_cov = __ballot((f & 3u) == 3u);
+        const unsigned long long m_mod = __ballot((f & 7u) == 7u);
+        if (head && (f & 1u)) {
+            // run = [lane, next head)
+            const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+            const int len = above ? __ffsll((long long)above) : 64 - lane;
+            const unsigned long long run = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << lane;
+            atomicAdd(touch + q, __popcll(m_touch & run));
+            const int nc = __popcll(m_cov & run);
+            if (nc) atomicAdd(cov + q, nc);
+            const int nm = __popcll(m_mod & run);
+            if (nm) atomicAdd(mod + q, nm);
         }
     }
 }

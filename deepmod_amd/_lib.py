@@ -46,6 +46,9 @@ SIGNATURES = [
     ("dm_summary_reduce_rccl", _c.c_int, [_vp, _vp, _c.c_int, _c.c_int]),
     ("dm_summary_fetch", _c.c_int, [_vp, _vp, _vp, _vp]),
     ("dm_summary_device_ptr", _vp, [_vp]),
+    ("dm_cluster_create", _vp, [_c.c_int, _vp, _c.c_size_t]),
+    ("dm_cluster_destroy", None, [_vp]),
+    ("dm_cluster_predict", _c.c_int, [_vp, _vp, _i64, _vp]),
 ]
 
 

@@ -172,6 +172,44 @@ __global__ void summary_add_kernel(int* __restrict__ touch, int* __restrict__ co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// CpG-cluster MLP (hm_cluster_predict.py:94-103): one row per thread, weights broadcast from LDS,
+// k-ascending fp32 accumulation.  60 B in/out per row, 3,420 FMA per row: VALU-bound, tiny.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cluster_mlp_kernel(const float* __restrict__ w, const float* __restrict__ x,
+                                                          const long long n, float* __restrict__ out) {
+    __shared__ float lw[DM_CLUSTER_WEIGHT_FLOATS];
+    for (int i = threadIdx.x; i < DM_CLUSTER_WEIGHT_FLOATS; i += blockDim.x) lw[i] = w[i];
+    __syncthreads();
+    const float* W1 = lw;             // [14][100]
+    const float* b1 = lw + 1400;      // [100]
+    const float* W2 = lw + 1500;      // [100][20]
+    const float* b2 = lw + 3500;      // [20]
+    const float* WO = lw + 3520;      // [20]
+    const float bO = lw[3540];
+    for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
+        float xi[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) xi[k] = x[r * 14 + k];
+        float h2[20];
+#pragma unroll
+        for (int j = 0; j < 20; ++j) h2[j] = 0.0f;
+        for (int u = 0; u < 100; ++u) {
+            float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 14; ++k) a = fmaf(xi[k], W1[k * 100 + u], a);
+            a = fmaxf(a + b1[u], 0.0f);                 // layer_1 = relu(X W_1 + b_1); dropout(keep_prob 1) = identity
+#pragma unroll
+            for (int j = 0; j < 20; ++j) h2[j] = fmaf(a, W2[u * 20 + j], h2[j]);
+        }
+        float o = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 20; ++j) o = fmaf(fmaxf(h2[j] + b2[j], 0.0f), WO[j], o);   // layer_2 = relu(.), then W_O
+        o += bO;
+        out[r] = 1.0f / (1.0f + expf(-o));              // output = sigmoid(.)
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -663,6 +701,79 @@ int dm_summary_fetch(dm_summary* s, int32_t* touch, int32_t* cov, int32_t* mod) 
 }
 
 void* dm_summary_device_ptr(dm_summary* s) { return s ? s->d_counts : nullptr; }
+
+// ------------------------------------------------------------------------------- cluster ----
+struct dm_cluster {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float* d_w = nullptr;
+    float* d_x = nullptr;
+    float* d_out = nullptr;
+    int64_t cap = 0;
+};
+
+dm_cluster* dm_cluster_create(int device, const float* weights, size_t n_floats) {
+    if (!weights || n_floats != DM_CLUSTER_WEIGHT_FLOATS) {
+        fail(DM_EINVAL, "cluster weights: expected %d floats, got %zu", DM_CLUSTER_WEIGHT_FLOATS, n_floats);
+        return nullptr;
+    }
+    dm_cluster* c = new (std::nothrow) dm_cluster();
+    if (!c) {
+        fail(DM_ENOMEM, "out of host memory");
+        return nullptr;
+    }
+    c->device = device;
+    bool ok = hipSetDevice(device) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc(&c->d_w, sizeof(float) * n_floats) == hipSuccess &&
+              hipMemcpy(c->d_w, weights, sizeof(float) * n_floats, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        fail(DM_EDEVICE, "cluster model setup on device %d failed: %s", device, hipGetErrorString(hipGetLastError()));
+        dm_cluster_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void dm_cluster_destroy(dm_cluster* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipFree(c->d_w);
+    (void)hipFree(c->d_x);
+    (void)hipFree(c->d_out);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dm_cluster_predict(dm_cluster* c, const float* x, int64_t n, float* out) {
+    if (!c) return fail(DM_EINVAL, "null cluster model");
+    if (n < 0) return fail(DM_EINVAL, "negative row count");
+    if (n == 0) return DM_OK;
+    if (!x || !out) return fail(DM_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    const bool xd = is_device_ptr(x), od = is_device_ptr(out);
+    if ((!xd || !od) && n > c->cap) {
+        (void)hipFree(c->d_x);
+        (void)hipFree(c->d_out);
+        c->d_x = c->d_out = nullptr;
+        HIP_TRY(hipMalloc(&c->d_x, sizeof(float) * 14 * n));
+        HIP_TRY(hipMalloc(&c->d_out, sizeof(float) * n));
+        c->cap = n;
+    }
+    const float* dx = x;
+    float* dout = out;
+    if (!xd) {
+        HIP_TRY(hipMemcpyAsync(c->d_x, x, sizeof(float) * 14 * n, hipMemcpyHostToDevice, c->stream));
+        dx = c->d_x;
+    }
+    if (!od) dout = c->d_out;
+    const int blocks = int(std::min<int64_t>((n + 255) / 256, 4096));
+    hipLaunchKernelGGL(cluster_mlp_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_w, dx, (long long)n, dout);
+    HIP_TRY(hipGetLastError());
+    if (!od) HIP_TRY(hipMemcpyAsync(out, c->d_out, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DM_OK;
+}
 
 // ---- RCCL, loaded lazily so single-GPU users never need it ---------------------------------
 namespace {

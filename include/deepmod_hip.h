@@ -23,6 +23,8 @@
  *        sum_handler's per-base accumulation    bin/DeepMod_scripts/myDetect.py:1089-1100
  *   dm_summary_reduce_rccl
  *        cross-process additive merge           DeepMod_tools/sum_chr_mod.py:47-52
+ *   dm_cluster_create / _predict / _destroy
+ *        cluster MLP sess.run([output])         DeepMod_tools/hm_cluster_predict.py:94-103, :158-164
  */
 #ifndef DEEPMOD_HIP_H
 #define DEEPMOD_HIP_H
@@ -132,6 +134,19 @@ int dm_summary_reduce_rccl(dm_summary* s, const void* unique_id128, int rank, in
 int dm_summary_fetch(dm_summary* s, int32_t* touch, int32_t* cov, int32_t* mod);
 /* raw device pointers (3 * length int32: touch | cov | mod) for callers that run their own collective */
 void* dm_summary_device_ptr(dm_summary* s);
+
+/* ------------------------------------------------------------- CpG cluster second stage -- */
+/*
+ * MLP 14 -> 100 (relu) -> 20 (relu) -> 1 (sigmoid) of DeepMod_tools/hm_cluster_predict.py:94-103,:161
+ * (graph nodes X, W_1/b_1, W_2/b_2, W_O/b_O, output; dropout with keep_prob = 1 is the identity).
+ * weights: 3541 floats = W_1[14][100], b_1[100], W_2[100][20], b_2[20], W_O[20][1], b_O[1] (host).
+ * x: [n][14] fp32, out: [n] fp32; host or device pointers.
+ */
+#define DM_CLUSTER_WEIGHT_FLOATS 3541
+typedef struct dm_cluster dm_cluster;
+dm_cluster* dm_cluster_create(int device, const float* weights, size_t n_floats);
+void dm_cluster_destroy(dm_cluster* c);
+int dm_cluster_predict(dm_cluster* c, const float* x, int64_t n, float* out);
 
 #ifdef __cplusplus
 }

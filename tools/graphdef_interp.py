@@ -180,7 +180,7 @@ class GraphRunner:
         g = self._tensor
         if op == "Placeholder":
             key = nd.name if nd.name in self.feeds else nd.name + ":0"
-            return np.asarray(self.feeds[key], dtype=np.float32)
+            return np.asarray(self.feeds[key], dtype=np.float32)   # TF casts the feed to the placeholder dtype
         if op in ("VariableV2", "Variable"):
             return np.asarray(self.vars[nd.name], dtype=np.float32)
         if op == "Identity":
@@ -211,6 +211,17 @@ class GraphRunner:
             axis = int(g(ins[0]))
             num = _attr_int(nd.attr["num_split"])
             return np.split(g(ins[1]), num, axis=axis)
+        if op == "Relu":
+            return np.maximum(g(ins[0]), np.float32(0)).astype(np.float32)
+        if op == "RealDiv":
+            return (g(ins[0]) / np.asarray(g(ins[1]), np.float32)).astype(np.float32)
+        if op == "Sub":
+            return (g(ins[0]) - g(ins[1])).astype(np.float32)
+        if op == "Floor":
+            return np.floor(g(ins[0])).astype(np.float32)
+        if op == "RandomUniform":
+            shape = np.asarray(g(ins[0])).astype(int).tolist()
+            return np.random.default_rng(0).random(shape, dtype=np.float32)   # [0,1): with keep_prob = 1 the mask is all ones
         if op == "Sigmoid":
             x = g(ins[0]).astype(np.float32)
             return (np.float32(1) / (np.float32(1) + np.exp(-x))).astype(np.float32)

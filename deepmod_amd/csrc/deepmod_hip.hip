@@ -223,6 +223,7 @@ struct dm_model {
     float* d_bpack = nullptr;
     float* d_hpack = nullptr;
     float* d_scratch = nullptr;
+    unsigned long long* d_dbg = nullptr;  // DM_TIMING builds only
     float bout[2] = {0, 0};
     int grid_cap = 0;
     // staging for host-pointer callers
@@ -296,6 +297,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
     p.cls = d_cls;
     p.scratch = m->d_scratch;
     p.ntiles = int((n + TILE_M - 1) / TILE_M);
+    p.dbg = m->d_dbg;
     const int grid = std::min(p.ntiles, m->grid_cap);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->profile) {
@@ -408,6 +410,10 @@ int model_init(dm_model* m, const float* weights) {
     const size_t scratch_bytes = size_t(m->grid_cap) * SCRATCH_FLOATS_PER_WG * sizeof(float);
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
     HIP_TRY(hipMemset(m->d_scratch, 0, scratch_bytes));
+#ifdef DM_TIMING
+    HIP_TRY(hipMalloc(&m->d_dbg, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(m->d_dbg, 0, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long)));
+#endif
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_f32_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_BYTES)));
     return DM_OK;
@@ -475,6 +481,7 @@ void dm_model_destroy(dm_model* m) {
     (void)hipFree(m->d_bpack);
     (void)hipFree(m->d_hpack);
     (void)hipFree(m->d_scratch);
+    (void)hipFree(m->d_dbg);
     (void)hipFree(m->d_x);
     (void)hipFree(m->d_prob);
     (void)hipFree(m->d_cls);
@@ -515,6 +522,14 @@ int dm_predict_read(dm_model* m, const float* rows, int64_t m_rows, int64_t firs
     // host rows: ship only the rows this call needs
     const float* base = rows + (first - DM_WINDOW / 2) * DM_NFEAT;
     return predict_common(m, base, DM_NFEAT, (count + DM_WINDOW - 1) * DM_NFEAT, count, prob, cls, false);
+}
+
+// debug builds (-DDM_TIMING): copy the per-wave section cycle counters [grid][waves][8]; returns element count
+extern "C" long long dm_debug_timing(dm_model* m, unsigned long long* out, long long cap) {
+    if (!m || !m->d_dbg) return 0;
+    const long long n = (long long)m->grid_cap * lstm32::WAVES * 8;
+    if (out && cap >= n) (void)hipMemcpy(out, m->d_dbg, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    return n;
 }
 
 int dm_model_sync(dm_model* m) {

@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ABL = os.path.join(ROOT, "tools", "_abl")
 VARIANTS = {
     "base": [],
+    "timing": ["-DDM_TIMING"],
     "nopeel": ["-DDM_ABL_NOPEEL"],
     "noepi": ["-DDM_ABL_NOEPI"],
     "noseq": ["-DDM_ABL_NOSEQ"],
@@ -55,6 +56,22 @@ def run(names, n=65536, reps=6):
         res[name] = ms / launches
         print("%-14s %.3f ms/launch  %.3g windows/s  %.1f%% of fp32 MFMA peak" %
               (name, res[name], n / res[name] * 1e3, n * 8.924e6 / (res[name] * 1e-3) / 157.3e12 * 100), flush=True)
+        if name.startswith("timing"):
+            import ctypes
+            lib = _lib.load()
+            lib.dm_debug_timing.restype = ctypes.c_longlong
+            lib.dm_debug_timing.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong]
+            cnt = lib.dm_debug_timing(m._h, None, 0)
+            buf = np.zeros(cnt, np.uint64)
+            lib.dm_debug_timing(m._h, buf.ctypes.data, cnt)
+            t = buf.reshape(-1, 8).astype(np.float64)
+            t = t[t[:, 6] > 0]
+            tot = t[:, 6].mean()
+            names = ["chunk prologue (A operand, DMA issue)", "chunk MFMA block", "dma wait (vmcnt 0)", "barrier",
+                     "pass prologue", "step epilogue (cell update, bias re-init, publish)", "kernel total"]
+            for i, nm in enumerate(names):
+                print("   %-52s %12.0f cycles  %5.1f%%" % (nm, t[:, i].mean(), 100 * t[:, i].mean() / tot))
+            print("   unaccounted %.1f%%" % (100 * (tot - t[:, :6].sum(axis=1).mean()) / tot))
         m.close(); dx.free(); dc.free()
     return res
 

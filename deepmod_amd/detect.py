@@ -71,8 +71,12 @@ def mPredict1(moptions, sp_options, sp_param, mfeatures, base_map_info, readk, s
         outs = [sess.run([mfpred], feed_dict={X: xs, Y: ys})[0] for xs, ys in zip(x_sub_group, y_sub_group)]
         mfpred_output = np.concatenate(outs, axis=0)
 
-    # associate predictions with aligned read bases: the k-th aligned event is the k-th row whose
-    # readbase is not '-' (myDetect.py:824-833)
+    return scatter_predictions(modevents, base_map_info, start_clip, n, mfpred_output)
+
+
+def scatter_predictions(modevents, base_map_info, start_clip, n, mfpred_output):
+    """The class -> aligned-read-base association of myDetect.py:824-833 (vectorised): the k-th
+    aligned event is the k-th row whose readbase is not '-'.  Returns pred_mod_num."""
     aligned = np.flatnonzero(base_map_info['readbase'] != '-')[:n]
     if len(aligned) < n:
         raise IndexError('base_map_info has %d aligned read bases but %d events are aligned' % (len(aligned), n))
@@ -83,6 +87,36 @@ def mPredict1(moptions, sp_options, sp_param, mfeatures, base_map_info, readk, s
     hit = aligned[np.asarray(mfpred_output) == 1]
     base_map_info['mod_pred'][hit] = 1
     return int(len(hit))
+
+
+def mPredict_batch(moptions, sp_options, reads):
+    """Classify several reads with ONE device call.  A read of n aligned bases is only n/128 tiles and
+    every tile has a fixed latency, so per-read calls (the reference's granularity, mPredict1) leave most
+    of the GPU idle; the reads' feature matrices already carry 100 all-zero rows on both sides
+    (myDetect.py:850-851), so they are concatenated and every row in between is classified in one
+    dm_predict_read; windows centred on padding rows are computed and dropped (~200/(n+200) of the work).
+    Results are identical to calling mPredict1 read by read (windows are independent).
+    reads: dicts with mfeatures, base_map_info, events, start_clip, end_clip.  Returns [pred_mod_num]."""
+    sess, X, Y, init_l, mfpred = sp_options['rnn']
+    half = int(moptions['windowsize'] / 2)
+    mats, spans, off = [], [], 0
+    for rd in reads:
+        tx = np.ascontiguousarray(rd['mfeatures'][:, 3:], dtype=np.float32)
+        n = len(rd['events']) - rd['end_clip'] - rd['start_clip']
+        mats.append(tx)
+        spans.append((off + 100, n))                  # first window centre (mind = 100) and count
+        off += len(tx)
+    rows = np.concatenate(mats)
+    sess.run(init_l)
+    _, cls = sess.model.predict_read(rows, half, len(rows) - 2 * half, want_prob=False)
+    out = []
+    for rd, (first, n) in zip(reads, spans):
+        if n <= 0:
+            out.append(0)
+            continue
+        out.append(scatter_predictions(rd['events'], rd['base_map_info'], rd['start_clip'], n,
+                                       cls[first - half:first - half + n]))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -99,19 +133,27 @@ def mDetect1(moptions, sp_options, container_files):
         except Exception:
             sp_options["Error"]["Cannot open container"].append(cf)
             continue
-        for read_ind, rd in enumerate(reads):
-            sp_param = {'f5data': {rd['readk']: (None, rd['events'], None, cf)}, 'f5status': ''}
+        good = []
+        for rd in reads:
             if len(rd['events']) - rd['start_clip'] - rd['end_clip'] < 50:           # myDetect.py:702-705
                 sp_options["Error"]["Less Event"].append(cf)
-                continue
-            bmi = rd['base_map_info']
-            try:
-                pred_mod_num = mPredict1(moptions, sp_options, sp_param, rd['mfeatures'], bmi, rd['readk'],
-                                         rd['start_clip'], rd['end_clip'])
-            except Exception as exc:  # same (reason -> files) error channel as the reference
-                sp_options["Error"]["Prediction failed: %s" % type(exc).__name__].append(cf)
-                continue
-            key = store.add(rd, bmi, pred_mod_num, cf, moptions)
+            else:
+                good.append(rd)
+        if not good:
+            continue
+        try:      # one device call for all reads of the container (see mPredict_batch)
+            sess = sp_options['rnn'][0]
+            if hasattr(sess, 'model') and getattr(sess, 'model') is not None:
+                pred_nums = mPredict_batch(moptions, sp_options, good)
+            else:
+                pred_nums = [mPredict1(moptions, sp_options, {'f5data': {rd['readk']: (None, rd['events'], None, cf)}},
+                                       rd['mfeatures'], rd['base_map_info'], rd['readk'], rd['start_clip'], rd['end_clip'])
+                             for rd in good]
+        except Exception as exc:  # same (reason -> files) error channel as the reference
+            sp_options["Error"]["Prediction failed: %s" % type(exc).__name__].append(cf)
+            continue
+        for rd, pred_mod_num in zip(good, pred_nums):
+            key = store.add(rd, rd['base_map_info'], pred_mod_num, cf, moptions)
             sp_options['Mod'].append([rd['chr'], rd['strand'], rd['mapped_start'], key,
                                       os.path.relpath(cf, moptions['wrkBase']), store.relpath(moptions)])
     store.close()

@@ -173,3 +173,27 @@ def test_bench_distributed_path_single_rank(gpu_device):
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["config"]["forced_dist_dry_run"] is True
     assert out["value"] > 1e6 and out["summary_check"]["touch"] > 0
+
+
+def test_batched_reads_equal_per_read_calls(models, tmp_path, gpu_device):
+    """mPredict_batch (one device call for many reads, concatenated feature matrices) must give exactly
+    what the reference-granularity mPredict1 gives read by read."""
+    import copy
+    from deepmod_amd import detect, predstore, synth_reads
+    prefix = str(tmp_path / "mod_train_synth")
+    synth.write_synthetic_checkpoint(prefix, seed=9, scale=4.0)
+    _, init_l, _, _, _, X, Y, _, _, _, _, mfpred = model.mCreateSession(7, 100, 21, {"outputlayer": ""})
+    sess = model.new_session(gpu_device)
+    sess.restore(prefix)
+    files = synth_reads.write_synthetic_run(str(tmp_path / "reads"), n_reads=7, reads_per_file=7, genome_len=20000, seed=4,
+                                            chrom="chrS", min_len=200, max_len=900)
+    reads = predstore.load_feature_container(files[0])
+    sp_options = {"rnn": (sess, X, Y, init_l, mfpred)}
+    batch_reads = copy.deepcopy(reads)
+    nums_b = detect.mPredict_batch({"windowsize": 21}, sp_options, batch_reads)
+    for rd, rb, nb in zip(reads, batch_reads, nums_b):
+        n1 = detect.mPredict1({"windowsize": 21}, sp_options, {"f5data": {rd["readk"]: (None, rd["events"], None, "f")}},
+                              rd["mfeatures"], rd["base_map_info"], rd["readk"], rd["start_clip"], rd["end_clip"])
+        assert n1 == nb and n1 > 0
+        assert np.array_equal(rd["base_map_info"]["mod_pred"], rb["base_map_info"]["mod_pred"])
+    sess.close()

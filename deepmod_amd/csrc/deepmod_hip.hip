@@ -229,6 +229,8 @@ struct dm_model {
     // staging for host-pointer callers
     static constexpr int64_t STAGE_WINDOWS = 65536;
     float* d_x = nullptr;
+    float* d_x2 = nullptr;       // second staging buffer: H2D of batch i+1 overlaps the kernel of batch i
+    hipStream_t copy_stream = nullptr;
     float* d_prob = nullptr;
     uint8_t* d_cls = nullptr;
     int64_t stage_rows = 0;  // capacity of d_x in floats
@@ -366,20 +368,35 @@ int predict_common(dm_model* m, const float* x, long long xstride, int64_t x_flo
         }
         return DM_OK;
     }
-    int rc = ensure_stage(m, int64_t(dm_model::STAGE_WINDOWS) * DM_WINDOW * DM_NFEAT);
+    const int64_t stage_floats = int64_t(dm_model::STAGE_WINDOWS) * DM_WINDOW * DM_NFEAT;
+    int rc = ensure_stage(m, stage_floats);
     if (rc) return rc;
-    for (int64_t off = 0; off < n; off += dm_model::STAGE_WINDOWS) {
+    if (!xdev && !m->d_x2) {
+        HIP_TRY(hipMalloc(&m->d_x2, sizeof(float) * stage_floats));
+        HIP_TRY(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+    }
+    float* stage[2] = {m->d_x, m->d_x2};
+    const int64_t win_floats = DM_WINDOW * DM_NFEAT;
+    if (!xdev) {   // prime the pipeline: batch 0
+        const int64_t cnt0 = std::min<int64_t>(dm_model::STAGE_WINDOWS, n);
+        HIP_TRY(hipMemcpyAsync(stage[0], x, sizeof(float) * cnt0 * win_floats, hipMemcpyHostToDevice, m->copy_stream));
+        HIP_TRY(hipStreamSynchronize(m->copy_stream));
+    }
+    int b = 0;
+    for (int64_t off = 0; off < n; off += dm_model::STAGE_WINDOWS, b ^= 1) {
         const int64_t cnt = std::min<int64_t>(dm_model::STAGE_WINDOWS, n - off);
-        const float* dx = x + off * xstride;
-        if (!xdev) {
-            HIP_TRY(hipMemcpyAsync(m->d_x, x + off * xstride, sizeof(float) * cnt * DM_WINDOW * DM_NFEAT,
-                                   hipMemcpyHostToDevice, m->stream));
-            dx = m->d_x;
-        }
+        const float* dx = xdev ? x + off * xstride : stage[b];
         float* dp = prob ? (pdev ? prob + 2 * off : m->d_prob) : nullptr;
         uint8_t* dc = cls ? (cdev ? cls + off : m->d_cls) : nullptr;
-        rc = launch_bilstm(m, dx, xstride, cnt, dp, dc);
+        rc = launch_bilstm(m, dx, xstride, cnt, dp, dc);          // asynchronous on the model's stream
         if (rc) return rc;
+        const int64_t noff = off + dm_model::STAGE_WINDOWS;
+        if (!xdev && noff < n) {                                  // upload the next batch meanwhile
+            const int64_t ncnt = std::min<int64_t>(dm_model::STAGE_WINDOWS, n - noff);
+            HIP_TRY(hipMemcpyAsync(stage[b ^ 1], x + noff * xstride, sizeof(float) * ncnt * win_floats,
+                                   hipMemcpyHostToDevice, m->copy_stream));
+            HIP_TRY(hipStreamSynchronize(m->copy_stream));
+        }
         if (prob && !pdev)
             HIP_TRY(hipMemcpyAsync(prob + 2 * off, m->d_prob, sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost, m->stream));
         if (cls && !cdev) HIP_TRY(hipMemcpyAsync(cls + off, m->d_cls, cnt, hipMemcpyDeviceToHost, m->stream));
@@ -483,6 +500,8 @@ void dm_model_destroy(dm_model* m) {
     (void)hipFree(m->d_scratch);
     (void)hipFree(m->d_dbg);
     (void)hipFree(m->d_x);
+    (void)hipFree(m->d_x2);
+    if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
     (void)hipFree(m->d_prob);
     (void)hipFree(m->d_cls);
     if (m->stream) (void)hipStreamDestroy(m->stream);

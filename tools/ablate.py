@@ -10,7 +10,9 @@ ABL = os.path.join(ROOT, "tools", "_abl")
 VARIANTS = {
     "base": [],
     "timing": ["-DDM_TIMING"],
-    "nopeel": ["-DDM_ABL_NOPEEL"],
+    "nodefer": ["-DDM_ABL_NODEFER"],
+    "noprio": ["-DDM_ABL_NOPRIO"],
+    "noprio_nodefer": ["-DDM_ABL_NOPRIO", "-DDM_ABL_NODEFER"],
     "noepi": ["-DDM_ABL_NOEPI"],
     "noseq": ["-DDM_ABL_NOSEQ"],
     "nobar": ["-DDM_ABL_NOBAR"],

@@ -10,9 +10,6 @@ ABL = os.path.join(ROOT, "tools", "_abl")
 VARIANTS = {
     "base": [],
     "timing": ["-DDM_TIMING"],
-    "nodefer": ["-DDM_ABL_NODEFER"],
-    "noprio": ["-DDM_ABL_NOPRIO"],
-    "noprio_nodefer": ["-DDM_ABL_NOPRIO", "-DDM_ABL_NODEFER"],
     "noepi": ["-DDM_ABL_NOEPI"],
     "noseq": ["-DDM_ABL_NOSEQ"],
     "nobar": ["-DDM_ABL_NOBAR"],

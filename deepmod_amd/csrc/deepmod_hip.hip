@@ -14,6 +14,7 @@
 
 #include "../../include/deepmod_hip.h"
 #include "lstm_f32.hip.inc"
+#include "lstm_f16.hip.inc"
 
 namespace {
 
@@ -114,6 +115,52 @@ Packed pack_weights(const float* flat) {
             }
     P.bout[0] = bo[0];
     P.bout[1] = bo[1];
+    return P;
+}
+
+// split-f16 packing: [dir][stream position][tile][hi|lo][lane][8 x f16], k-steps in the kernel's stream order
+struct Packed16 {
+    std::vector<unsigned char> w;
+};
+
+Packed16 pack_weights_f16(const float* flat) {
+    using namespace lstm16;
+    Packed16 P;
+    P.w.assign(size_t(2) * KS_DIR * KSTEP_BYTES, 0);
+    const float* p = flat;
+    for (int d = 0; d < 2; ++d) {
+        int ks_base = 0;
+        for (int l = 0; l < 3; ++l) {
+            const int kin = l == 0 ? NFEAT : HID;
+            const int nks = l == 0 ? KS_L0 : KS_L12;
+            const float* kern = p;
+            p += size_t(kin + HID) * 400 + 400;
+            static const int order12[7] = {4, 5, 6, 3, 0, 1, 2};
+            for (int i = 0; i < nks; ++i) {
+                const int ks = l == 0 ? i : order12[i];
+                _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + size_t(d * KS_DIR + ks_base + i) * KSTEP_BYTES);
+                for (int t = 0; t < NT; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = 32 * ks + 8 * (lane >> 4) + j;
+                            int krow = -1;   // row of the TF kernel; -1 = zero padding
+                            if (l == 0) {
+                                if (k < HID) krow = NFEAT + k;                                  // own h
+                                else if (k >= 8 * KG_H && k < 8 * KG_H + NFEAT) krow = k - 8 * KG_H;   // x features
+                            } else {
+                                if (k < HID) krow = k;                                          // h of the layer below
+                                else if (k >= 8 * KG_H && k < 8 * KG_H + HID) krow = HID + (k - 8 * KG_H);   // own h
+                            }
+                            const float v = krow < 0 ? 0.0f : kern[size_t(krow) * 400 + gate_col(t, lane & 15)];
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)(v - (float)hi);
+                            dst[((size_t(t) * 2 + 0) * 64 + lane) * 8 + j] = hi;
+                            dst[((size_t(t) * 2 + 1) * 64 + lane) * 8 + j] = lo;
+                        }
+            }
+            ks_base += nks;
+        }
+    }
     return P;
 }
 
@@ -222,10 +269,13 @@ struct dm_model {
     float* d_wpack = nullptr;
     float* d_bpack = nullptr;
     float* d_hpack = nullptr;
+    unsigned char* d_wpack16 = nullptr;   // split-f16 weights (DM_PREC_F16X3)
+    float* d_wout = nullptr;              // head W[200][2] fp32 (DM_PREC_F16X3)
     float* d_scratch = nullptr;
     unsigned long long* d_dbg = nullptr;  // DM_TIMING builds only
     float bout[2] = {0, 0};
     int grid_cap = 0;
+    std::vector<float> host_weights;      // canonical blob, kept for lazy packing of other precisions
     // staging for host-pointer callers
     static constexpr int64_t STAGE_WINDOWS = 65536;
     float* d_x = nullptr;
@@ -281,26 +331,22 @@ int flush_profile(dm_model* m) {
     return DM_OK;
 }
 
+int ensure_f16(dm_model* m) {
+    if (m->d_wpack16) return DM_OK;
+    Packed16 P = pack_weights_f16(m->host_weights.data());
+    HIP_TRY(hipMalloc(&m->d_wpack16, P.w.size()));
+    HIP_TRY(hipMemcpy(m->d_wpack16, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
+    const float* wout = m->host_weights.data() + (DM_WEIGHT_FLOATS - 402);
+    HIP_TRY(hipMalloc(&m->d_wout, 400 * sizeof(float)));
+    HIP_TRY(hipMemcpy(m->d_wout, wout, 400 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16::bilstm_f16x3_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16::LDS_BYTES)));
+    return DM_OK;
+}
+
 // launch on device-resident buffers
 int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, float* d_prob, uint8_t* d_cls) {
-    using namespace lstm32;
     if (n <= 0) return DM_OK;
-    if (m->precision != DM_PREC_F32) return fail(DM_ESTATE, "precision mode %d not available in this build", m->precision);
-    Params p;
-    p.wpack = m->d_wpack;
-    p.bpack = m->d_bpack;
-    p.hpack = m->d_hpack;
-    p.bout0 = m->bout[0];
-    p.bout1 = m->bout[1];
-    p.x = d_x;
-    p.xstride = xstride;
-    p.n = n;
-    p.prob = d_prob;
-    p.cls = d_cls;
-    p.scratch = m->d_scratch;
-    p.ntiles = int((n + TILE_M - 1) / TILE_M);
-    p.dbg = m->d_dbg;
-    const int grid = std::min(p.ntiles, m->grid_cap);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->profile) {
         if (m->events_used == m->events.size()) {
@@ -319,7 +365,44 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         ++m->events_used;
         HIP_TRY(hipEventRecord(e0, m->stream));
     }
-    hipLaunchKernelGGL(bilstm_f32_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
+    if (m->precision == DM_PREC_F16X3) {
+        using namespace lstm16;
+        int rc = ensure_f16(m);
+        if (rc) return rc;
+        Params p;
+        p.wpack = m->d_wpack16;
+        p.bpack = m->d_bpack;
+        p.hpack = m->d_wout;
+        p.bout0 = m->bout[0];
+        p.bout1 = m->bout[1];
+        p.x = d_x;
+        p.xstride = xstride;
+        p.n = n;
+        p.prob = d_prob;
+        p.cls = d_cls;
+        p.scratch = reinterpret_cast<unsigned char*>(m->d_scratch);
+        p.ntiles = int((n + TILE_M - 1) / TILE_M);
+        const int grid = std::min(p.ntiles, m->grid_cap);
+        hipLaunchKernelGGL(bilstm_f16x3_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
+    } else {
+        using namespace lstm32;
+        Params p;
+        p.wpack = m->d_wpack;
+        p.bpack = m->d_bpack;
+        p.hpack = m->d_hpack;
+        p.bout0 = m->bout[0];
+        p.bout1 = m->bout[1];
+        p.x = d_x;
+        p.xstride = xstride;
+        p.n = n;
+        p.prob = d_prob;
+        p.cls = d_cls;
+        p.scratch = m->d_scratch;
+        p.ntiles = int((n + TILE_M - 1) / TILE_M);
+        p.dbg = m->d_dbg;
+        const int grid = std::min(p.ntiles, m->grid_cap);
+        hipLaunchKernelGGL(bilstm_f32_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
+    }
     HIP_TRY(hipGetLastError());
     if (m->profile) {
         HIP_TRY(hipEventRecord(e1, m->stream));
@@ -415,6 +498,7 @@ int model_init(dm_model* m, const float* weights) {
     m->num_cu = prop.multiProcessorCount;
     m->grid_cap = m->num_cu;  // 120 KB of LDS per workgroup -> one resident (persistent) workgroup per CU
     HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    m->host_weights.assign(weights, weights + DM_WEIGHT_FLOATS);
     Packed P = pack_weights(weights);
     m->bout[0] = P.bout[0];
     m->bout[1] = P.bout[1];
@@ -424,7 +508,7 @@ int model_init(dm_model* m, const float* weights) {
     HIP_TRY(hipMemcpy(m->d_wpack, P.w.data(), P.w.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_bpack, P.b.data(), P.b.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_hpack, P.h.data(), P.h.size() * sizeof(float), hipMemcpyHostToDevice));
-    const size_t scratch_bytes = size_t(m->grid_cap) * SCRATCH_FLOATS_PER_WG * sizeof(float);
+    const size_t scratch_bytes = size_t(m->grid_cap) * std::max(SCRATCH_FLOATS_PER_WG * sizeof(float), lstm16::SCRATCH_BYTES_PER_WG);
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
     HIP_TRY(hipMemset(m->d_scratch, 0, scratch_bytes));
 #ifdef DM_TIMING
@@ -498,6 +582,8 @@ void dm_model_destroy(dm_model* m) {
     (void)hipFree(m->d_bpack);
     (void)hipFree(m->d_hpack);
     (void)hipFree(m->d_scratch);
+    (void)hipFree(m->d_wpack16);
+    (void)hipFree(m->d_wout);
     (void)hipFree(m->d_dbg);
     (void)hipFree(m->d_x);
     (void)hipFree(m->d_x2);
@@ -515,7 +601,7 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
             m->profile = value != 0;
             return DM_OK;
         case DM_OPT_PRECISION:
-            if (value != DM_PREC_F32) return fail(DM_EINVAL, "precision %lld not available in this build", (long long)value);
+            if (value != DM_PREC_F32 && value != DM_PREC_F16X3) return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
             m->precision = int(value);
             return DM_OK;
         default:

@@ -26,15 +26,21 @@ def _check(prob, cls, ref_prob, ref_cls):
     return err
 
 
-@pytest.fixture(scope="module")
-def models(gpu_device):
+@pytest.fixture(scope="module", params=["f32", "f16x3"])
+def models(gpu_device, request):
+    """Every parity test runs for both precision modes of the library: exact-fp32 MFMA and the split-f16
+    (3 products per fp32 product) MFMA path.  Same tolerance for both."""
+    from deepmod_amd import _lib
+    prec = _lib.DM_PREC_F32 if request.param == "f32" else _lib.DM_PREC_F16X3
     cache = {}
 
     def get(seed, scale):
         key = (seed, scale)
         if key not in cache:
             w = synth.synthetic_weights(seed, scale)
-            cache[key] = (w, model.BiLSTMModel(w, device=gpu_device))
+            m = model.BiLSTMModel(w, device=gpu_device)
+            m.set_option(_lib.DM_OPT_PRECISION, prec)
+            cache[key] = (w, m)
         return cache[key]
     yield get
     for _, m in cache.values():

@@ -134,8 +134,10 @@ Packed16 pack_weights_f16(const float* flat) {
             const int kin = l == 0 ? NFEAT : HID;
             const int nks = l == 0 ? KS_L0 : KS_L12;
             const float* kern = p;
+            const float* bias = p + size_t(kin + HID) * 400;
             p += size_t(kin + HID) * 400 + 400;
             static const int order12[7] = {4, 5, 6, 3, 0, 1, 2};
+            const int own_k0 = l == 0 ? 0 : 8 * KG_H;     // k index of own hidden unit 0; unit slot 100 carries the constant 1.0
             for (int i = 0; i < nks; ++i) {
                 const int ks = l == 0 ? i : order12[i];
                 _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + size_t(d * KS_DIR + ks_base + i) * KSTEP_BYTES);
@@ -151,7 +153,9 @@ Packed16 pack_weights_f16(const float* flat) {
                                 if (k < HID) krow = k;                                          // h of the layer below
                                 else if (k >= 8 * KG_H && k < 8 * KG_H + HID) krow = HID + (k - 8 * KG_H);   // own h
                             }
-                            const float v = krow < 0 ? 0.0f : kern[size_t(krow) * 400 + gate_col(t, lane & 15)];
+                            const int gc = gate_col(t, lane & 15);
+                            float v = krow < 0 ? 0.0f : kern[size_t(krow) * 400 + gc];
+                            if (k == own_k0 + HID) v = bias[gc] + ((gc >= 200 && gc < 300) ? 1.0f : 0.0f);   // bias row (+ forget_bias)
                             const _Float16 hi = (_Float16)v;
                             const _Float16 lo = (_Float16)(v - (float)hi);
                             dst[((size_t(t) * 2 + 0) * 64 + lane) * 8 + j] = hi;
@@ -382,6 +386,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         p.cls = d_cls;
         p.scratch = reinterpret_cast<unsigned char*>(m->d_scratch);
         p.ntiles = int((n + TILE_M - 1) / TILE_M);
+        p.dbg = m->d_dbg;
         const int grid = std::min(p.ntiles, m->grid_cap);
         hipLaunchKernelGGL(bilstm_f16x3_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
     } else {

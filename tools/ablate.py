@@ -30,6 +30,9 @@ def build(names):
         print("built", out)
 
 
+PREC = int(os.environ.get('DM_ABL_PREC', '0'))
+
+
 def run(names, n=65536, reps=6):
     sys.path.insert(0, ROOT)
     import numpy as np
@@ -45,6 +48,7 @@ def run(names, n=65536, reps=6):
         _lib.LIB_PATH = path
         m = model.BiLSTMModel(w, 0)
         m.set_option(_lib.DM_OPT_PROFILE, 1)
+        m.set_option(_lib.DM_OPT_PRECISION, PREC)
         dx = model.DeviceArray.from_host(x, 0)
         dc = model.DeviceArray((n,), np.uint8, 0)
         m.predict_windows(dx, cls=dc, want_prob=False)
@@ -68,6 +72,8 @@ def run(names, n=65536, reps=6):
             tot = t[:, 6].mean()
             names = ["chunk prologue (A operand, DMA issue)", "chunk MFMA block", "dma wait (vmcnt 0)", "barrier",
                      "pass prologue", "step epilogue (cell update, bias re-init, publish)", "kernel total"]
+            if PREC == 1:
+                names[0] = "stage A-operand load (LDS slab / global / x)"
             for i, nm in enumerate(names):
                 print("   %-52s %12.0f cycles  %5.1f%%" % (nm, t[:, i].mean(), 100 * t[:, i].mean() / tot))
             print("   unaccounted %.1f%%" % (100 * (tot - t[:, :6].sum(axis=1).mean()) / tot))

@@ -156,6 +156,8 @@ Packed16 pack_weights_f16(const float* flat) {
                             const int gc = gate_col(t, lane & 15);
                             float v = krow < 0 ? 0.0f : kern[size_t(krow) * 400 + gc];
                             if (k == own_k0 + HID) v = bias[gc] + ((gc >= 200 && gc < 300) ? 1.0f : 0.0f);   // bias row (+ forget_bias)
+                            // exponent scales folded into the GEMM (lstm16::lstm_cells): i, f, o -> -log2(e), j -> 2 log2(e)
+                            v *= (gc >= 100 && gc < 200) ? 2.8853900817779268f : -1.4426950408889634f;
                             const _Float16 hi = (_Float16)v;
                             const _Float16 lo = (_Float16)(v - (float)hi);
                             dst[((size_t(t) * 2 + 0) * 64 + lane) * 8 + j] = hi;
@@ -516,7 +518,7 @@ int model_init(dm_model* m, const float* weights) {
     const size_t scratch_bytes = size_t(m->grid_cap) * std::max(SCRATCH_FLOATS_PER_WG * sizeof(float), lstm16::SCRATCH_BYTES_PER_WG);
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
     HIP_TRY(hipMemset(m->d_scratch, 0, scratch_bytes));
-#ifdef DM_TIMING
+#if defined(DM_TIMING) || defined(DM_TRACE)
     HIP_TRY(hipMalloc(&m->d_dbg, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(m->d_dbg, 0, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long)));
 #endif

@@ -14,6 +14,13 @@ VARIANTS = {
     "noseq": ["-DDM_ABL_NOSEQ"],
     "nobar": ["-DDM_ABL_NOBAR"],
     "nodma": ["-DDM_ABL_NODMA"],
+    "w8": ["-DDM16_WAVES=8", "-DDM16_MT=1"],
+    "w8timing": ["-DDM16_WAVES=8", "-DDM16_MT=1", "-DDM_TIMING"],
+    "w8trace": ["-DDM16_WAVES=8", "-DDM16_MT=1", "-DDM_TRACE"],
+    "w4trace": ["-DDM_TRACE"],
+    "w4trace_noldsb": ["-DDM_TRACE", "-DDM16_ABL_NOLDSB"],
+    "w4trace_nodma": ["-DDM_TRACE", "-DDM16_ABL_NODMA"],
+    "w4trace_neither": ["-DDM_TRACE", "-DDM16_ABL_NODMA", "-DDM16_ABL_NOLDSB"],
     "mfma_only": ["-DDM_ABL_NOEPI", "-DDM_ABL_NOBAR", "-DDM_ABL_NODMA", "-DDM_ABL_NOSEQ"],
 }
 EXTRA = sys.argv[3:] if len(sys.argv) > 3 else []
@@ -59,7 +66,22 @@ def run(names, n=65536, reps=6):
         res[name] = ms / launches
         print("%-14s %.3f ms/launch  %.3g windows/s  %.1f%% of fp32 MFMA peak" %
               (name, res[name], n / res[name] * 1e3, n * 8.924e6 / (res[name] * 1e-3) / 157.3e12 * 100), flush=True)
-        if name.startswith("timing"):
+        if "trace" in name:
+            import ctypes
+            lib = _lib.load()
+            lib.dm_debug_timing.restype = ctypes.c_longlong
+            lib.dm_debug_timing.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong]
+            cnt = lib.dm_debug_timing(m._h, None, 0)
+            buf = np.zeros(cnt, np.uint64)
+            lib.dm_debug_timing(m._h, buf.ctypes.data, cnt)
+            t = buf[:256].reshape(8, 32).astype(np.int64)
+            t = t[t[:, 0] > 0]
+            t0 = t[:, 0].min()
+            labels = ["stage start", "A loaded"] + sum([["k%d mfma end" % i, "k%d dma done" % i, "k%d barrier exit" % i] for i in range(7)], []) + ["epilogue end"]
+            print("   %-18s" % "event" + "".join("  wave%d" % w for w in range(len(t))))
+            for i, lb in enumerate(labels):
+                print("   %-18s" % lb + "".join("%7d" % (t[w, i] - t0) for w in range(len(t))))
+        if "timing" in name:
             import ctypes
             lib = _lib.load()
             lib.dm_debug_timing.restype = ctypes.c_longlong
@@ -76,6 +98,7 @@ def run(names, n=65536, reps=6):
                 names[0] = "stage A-operand load (LDS slab / global / x)"
             for i, nm in enumerate(names):
                 print("   %-52s %12.0f cycles  %5.1f%%" % (nm, t[:, i].mean(), 100 * t[:, i].mean() / tot))
+            print("   %-52s %12.0f cycles  %5.1f%%  (inside the epilogue)" % ("publish slab / head reduce", t[:, 7].mean(), 100 * t[:, 7].mean() / tot))
             print("   unaccounted %.1f%%" % (100 * (tot - t[:, :6].sum(axis=1).mean()) / tot))
         m.close(); dx.free(); dc.free()
     return res

@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from deepmod_amd import _lib, model, synth
 from oracle import oracle_np
+if os.environ.get('DM_LIB'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['DM_LIB'])
 for scale in (1.0, 4.0):
     w = synth.synthetic_weights(21, scale)
     m = model.BiLSTMModel(w, 0)

@@ -27,7 +27,15 @@ if ROOT not in sys.path:
 BATCH = 65536
 N_BATCHES = 16                # 16 x 65,536 = 1,048,576 windows ("10^6 windows batched 64k")
 FLOP_PER_WINDOW = 8.924e6     # 11 live steps x 2 dirs x 3 layers + head
-PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32
+# /opt/skills/guides/MI355X_MICROARCH.md dense MFMA peaks: v_mfma_f32_16x16x4_f32 157.3 TF, 16-bit (f16/bf16) 2.5 PF
+PRECISIONS = {
+    "f16x3": {"peak": 2500.0, "kernel": "lstm16::bilstm_f16x3_kernel", "dtype": "f16x3",
+              "label": "split-f16 MFMA (hi+lo f16 operands, 3 products per fp32 product, fp32 accumulate)",
+              "peak_note": "v_mfma_f32_16x16x32_f16 dense 16-bit peak 2.5 PF; the split issues 3 products x 576/507 K padding = "
+                           "3.41 matrix FLOP per algorithmic FLOP, so frac <= 0.293 by construction"},
+    "f32": {"peak": 157.3, "kernel": "lstm32::bilstm_f32_kernel", "dtype": "f32", "label": "fp32 MFMA",
+            "peak_note": "v_mfma_f32_16x16x4_f32 dense fp32, 157.3 TF"},
+}
 CONTIG_LEN = 4_641_652        # E. coli K-12 sized contig for the synthetic summary
 
 
@@ -69,11 +77,11 @@ def cpu_baseline(weights, x_sample_src):
                       % (reps, len(x_sample_src), n, cores, dt)}
 
 
-def measured_traffic():
+def measured_traffic(precision):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/<round>/pmc_summary.json: FETCH_SIZE and WRITE_SIZE in KB, separate --pmc passes;
-    gfx950 correction: FETCH_SIZE x 2 for wide coalesced reads, MI355X_MICROARCH.md HBM section)."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+    command (profiles/<round>/<precision>/pmc_summary.json: FETCH_SIZE and WRITE_SIZE in KB, separate --pmc
+    passes; gfx950 correction: FETCH_SIZE x 2 for wide coalesced reads, MI355X_MICROARCH.md HBM section)."""
+    path = os.path.join(ROOT, "profiles", "r01", precision, "pmc_summary.json")
     try:
         pmc = json.load(open(path))
         fetch = pmc["FETCH_SIZE"]["mean_per_launch"] * 1024.0
@@ -84,12 +92,45 @@ def measured_traffic():
         return None
 
 
+def extras(m, _lib, model, precision, x_dev0, x_host0, prob_dev, cls_dev, reps=4):
+    """Untimed-for-`value` side measurements on rank 0 at N = 1: the other MFMA mode on the same batch (kernel
+    time from HIP events) and the PCIe-inclusive rate when the boundary is handed pageable host buffers."""
+    out = {}
+    other = "f32" if precision == "f16x3" else "f16x3"
+    m.set_precision(other)
+    m.predict_windows(x_dev0, prob=prob_dev, cls=cls_dev)
+    m.sync()
+    m.profile_reset()
+    for _ in range(reps):
+        m.predict_windows(x_dev0, prob=prob_dev, cls=cls_dev)
+    m.sync()
+    ms, launches, kw = m.profile_get()
+    rate = kw / (ms * 1e-3)
+    Q = PRECISIONS[other]
+    out["other_precision"] = {"precision": other, "kernel": Q["kernel"], "avg_launch_ms": ms / max(launches, 1),
+                              "windows_per_s_kernel": rate, "achieved_tflops": rate * FLOP_PER_WINDOW / 1e12,
+                              "peak_tflops": Q["peak"], "frac": rate * FLOP_PER_WINDOW / 1e12 / Q["peak"]}
+    m.set_precision(precision)
+    m.predict_windows(x_host0)            # host in, host out: H2D + kernel + D2H, synchronous
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m.predict_windows(x_host0)
+    dt = time.perf_counter() - t0
+    out["host_buffers"] = {"value": reps * len(x_host0) / dt, "unit": "base-positions/s",
+                           "note": "dm_predict_windows on pageable host x[65536,21,7] fp32, prob+cls returned to host "
+                                   "(PCIe-inclusive, 588 B in + 9 B out per window); never used as `value`"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=sorted(PRECISIONS), default="f16x3",
+                    help="MFMA mode of the classifier kernel (both meet the 1e-4 probability tolerance)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (other precision, host-buffer rate)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,8 +156,9 @@ def main():
     device = local_rank if dist_mode else 0
 
     weights = synth.synthetic_weights(seed=7, scale=1.0)
-    m = model.BiLSTMModel(weights, device=device)
+    m = model.BiLSTMModel(weights, device=device, precision=args.precision)
     m.set_option(_lib.DM_OPT_PROFILE, 1)
+    P = PRECISIONS[args.precision]
 
     # synthetic windows, distinct per rank and per batch, resident in HBM before the timed region
     n_batches = min(N_BATCHES, max(1, args.steps))
@@ -187,25 +229,27 @@ def main():
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = (kwindows / max(launches, 1)) * FLOP_PER_WINDOW / avg_launch_s / 1e12
         touch, cov, mod = summ.fetch()
-        traffic = measured_traffic()
+        traffic = measured_traffic(args.precision)
         out = {
             "metric": "base-positions/sec (whole node), E. coli 5mC wd21/f7 BiLSTM",
             "value": value, "unit": "base-positions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": P["dtype"], "data": "synthetic",
             "config": {"workload": "configs[1]: rnn_conmodC_P100wd21_f7ne1u0_4 geometry (3x100 BiLSTM, wd21, f7), "
                                    "synthetic weights (real .data shards absent), %d windows/step resident in HBM, "
                                    "%d distinct batches (1,048,576 windows)" % (BATCH, n_batches),
                        "batch": BATCH, "windows_total": total_windows, "parallelism": "window-sharded x%d" % world, "forced_dist_dry_run": bool(dist_mode and world == 1),
-                       "precision": "f32 MFMA (exact)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": (traffic or {}).get("bytes"),
+                       "precision": P["label"]},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": P["peak"], "unit": "TFLOP/s",
+                         "frac": achieved / P["peak"], "traffic": (traffic or {}).get("bytes"),
                          "traffic_detail": traffic, "algorithmic_bytes": 596 * BATCH,
-                         "kernel": "lstm32::bilstm_f32_kernel", "avg_launch_ms": avg_launch_s * 1e3,
+                         "kernel": P["kernel"], "avg_launch_ms": avg_launch_s * 1e3,
                          "launches": launches, "flop_per_window": FLOP_PER_WINDOW,
-                         "peak_note": "v_mfma_f32_16x16x4_f32 dense fp32, 157.3 TF"},
+                         "peak_note": P["peak_note"]},
             "summary_check": {"touch": int(touch.sum()), "cov": int(cov.sum()), "mod": int(mod.sum())},
         }
+        if world == 1 and not args.no_extras:
+            out["extras"] = extras(m, _lib, model, args.precision, x_dev[0], x0, prob_dev, cls_dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(weights, x0)
         print(json.dumps(out), flush=True)

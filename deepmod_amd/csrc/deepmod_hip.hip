@@ -292,7 +292,7 @@ struct dm_model {
     int64_t stage_rows = 0;  // capacity of d_x in floats
     // profiling
     bool profile = false;
-    int precision = DM_PREC_F32;
+    int precision = DM_PREC_F16X3;        // default: fastest mode that meets the 1e-4 probability tolerance
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     double prof_ms = 0.0;

@@ -90,13 +90,24 @@ def _ptr(a):
 class BiLSTMModel:
     """One dm_model on one GPU (one per process, like the reference's one TF session per process)."""
 
-    def __init__(self, tensors: Dict[str, np.ndarray], device: int = 0):
+    PRECISIONS = {"f32": _lib.DM_PREC_F32, "f16x3": _lib.DM_PREC_F16X3}
+
+    def __init__(self, tensors: Dict[str, np.ndarray], device: int = 0, precision: Optional[str] = None):
         self._lib = _lib.load()
         self.device = device
         flat = flatten_weights(tensors)
         self._h = self._lib.dm_model_create(device, flat.ctypes.data, flat.size, NFEAT, HID, WIN, LAYERS)
         if not self._h:
             raise _lib.DeepModHipError("dm_model_create: " + _lib.last_error())
+        # library default is "f16x3" (split-f16 MFMA, fp32-class results); DEEPMOD_PRECISION=f32 selects the fp32 MFMA kernel
+        precision = precision or os.environ.get("DEEPMOD_PRECISION")
+        if precision:
+            self.set_precision(precision)
+
+    def set_precision(self, name: str):
+        if name not in self.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
+        self.set_option(_lib.DM_OPT_PRECISION, self.PRECISIONS[name])
 
     @classmethod
     def from_checkpoint(cls, prefix: str, device: int = 0) -> "BiLSTMModel":

@@ -52,9 +52,10 @@ extern "C" {
 
 /* dm_model_set_option keys */
 #define DM_OPT_PROFILE 1   /* 1: bracket every kernel launch with HIP events on the model's stream */
-#define DM_OPT_PRECISION 2 /* DM_PREC_* */
-#define DM_PREC_F32 0      /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
-#define DM_PREC_F16X3 1    /* split-f16 MFMA, 3 products per f32 product */
+#define DM_OPT_PRECISION 2 /* DM_PREC_*; default DM_PREC_F16X3 */
+#define DM_PREC_F32 0      /* fp32 MFMA (v_mfma_f32_16x16x4_f32): fp32 products, the TF graph's own arithmetic */
+#define DM_PREC_F16X3 1    /* split-f16 MFMA: every fp32 operand = hi + lo f16, 3 products per fp32 product, fp32
+                              accumulation; max |dp| vs the oracle 1e-6 .. 2e-6 (tolerance of the path: 1e-4), 2.5x faster */
 
 typedef struct dm_model dm_model;
 typedef struct dm_summary dm_summary;

@@ -14,13 +14,12 @@ VARIANTS = {
     "noseq": ["-DDM_ABL_NOSEQ"],
     "nobar": ["-DDM_ABL_NOBAR"],
     "nodma": ["-DDM_ABL_NODMA"],
-    "w8": ["-DDM16_WAVES=8", "-DDM16_MT=1"],
-    "w8timing": ["-DDM16_WAVES=8", "-DDM16_MT=1", "-DDM_TIMING"],
-    "w8trace": ["-DDM16_WAVES=8", "-DDM16_MT=1", "-DDM_TRACE"],
-    "w4trace": ["-DDM_TRACE"],
-    "w4trace_noldsb": ["-DDM_TRACE", "-DDM16_ABL_NOLDSB"],
-    "w4trace_nodma": ["-DDM_TRACE", "-DDM16_ABL_NODMA"],
-    "w4trace_neither": ["-DDM_TRACE", "-DDM16_ABL_NODMA", "-DDM16_ABL_NOLDSB"],
+    "trace": ["-DDM_TRACE"],                                   # f16x3 kernel: per-wave timeline of one stage
+    "w4": ["-DDM16_WAVES=4", "-DDM16_MT=2"],                   # f16x3 kernel: 4 waves x 2 M-tiles (one wave per SIMD)
+    "w4timing": ["-DDM16_WAVES=4", "-DDM16_MT=2", "-DDM_TIMING"],
+    "w4trace": ["-DDM16_WAVES=4", "-DDM16_MT=2", "-DDM_TRACE"],
+    "trace_noldsb": ["-DDM_TRACE", "-DDM16_ABL_NOLDSB"],
+    "trace_nodma": ["-DDM_TRACE", "-DDM16_ABL_NODMA"],
     "mfma_only": ["-DDM_ABL_NOEPI", "-DDM_ABL_NOBAR", "-DDM_ABL_NODMA", "-DDM_ABL_NOSEQ"],
 }
 EXTRA = sys.argv[3:] if len(sys.argv) > 3 else []

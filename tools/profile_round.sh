@@ -1,12 +1,13 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of the bench command.
-# Usage: bash tools/profile_round.sh <tag>     -> gpurun_out/prof_<tag>/...
+# Usage: bash tools/profile_round.sh <tag> [f16x3|f32]     -> gpurun_out/prof_<tag>/...
 TAG=${1:-final}
+PREC=${2:-f16x3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 8 --warmup 1 --no-cpu-baseline"
+B="python $R/bench.py --steps 8 --warmup 1 --no-cpu-baseline --no-extras --precision $PREC"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $B > $OUT/kt.log 2>&1; echo "kt rc=$?"
 for C in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" \

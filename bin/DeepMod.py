@@ -32,11 +32,11 @@ def build_parser():
     com.add_argument('--threads', type=int, default=4, help='number of worker processes')
     com.add_argument('--files_per_thread', type=int, default=1000, help='input files per worker batch')
     com.add_argument('--windowsize', type=int, default=21, help='window size (odd)')
-    com.add_argument('--alignStr', choices=['bwa', 'minimap2'], default='minimap2', help='accepted for compatibility')
+    com.add_argument('--alignStr', choices=['bwa', 'minimap2'], default='minimap2', help='aligner run on raw containers when on PATH; otherwise side-car <container>.sam files are read')
     com.add_argument('--SignalGroup', choices=['simple', 'rundif'], default='simple', help='accepted for compatibility')
     com.add_argument('--move', action='store_true', default=False, help='accepted for compatibility')
     det = sub.add_parser('detect', parents=[com], help='detect modifications')
-    det.add_argument('--Ref', help='reference genome (used by the out-of-scope aligner front end)')
+    det.add_argument('--Ref', help='reference genome FASTA (raw containers: reference bases of the aligned reads)')
     det.add_argument('--predDet', type=int, choices=[0, 1], default=1, help='1: predict + summarise; 0: summarise only')
     det.add_argument('--predpath', default=None, help='prediction folder for --predDet 0')
     det.add_argument('--modfile', default=None, help='checkpoint prefix of the trained model (TF bundle)')
@@ -44,8 +44,8 @@ def build_parser():
     det.add_argument('--hidden', type=int, default=100, help='LSTM hidden units')
     det.add_argument('--basecall_1d', default='Basecall_1D_000', help='accepted for compatibility')
     det.add_argument('--basecall_2strand', default='BaseCalled_template', help='accepted for compatibility')
-    det.add_argument('--region', default=None, help='accepted for compatibility')
-    det.add_argument('--ConUnk', default=True, help='accepted for compatibility')
+    det.add_argument('--region', default=None, help='regions of interest, e.g. chr1:1:100000;chr2:10000')
+    det.add_argument('--ConUnk', default=True, help='also process contigs whose names contain _ - / :')
     det.add_argument('--outputlayer', default='', choices=['', 'sigmoid'], help="only '' is built")
     det.add_argument('--Base', default='C', choices=['A', 'C', 'G', 'T'], help='base of interest')
     det.add_argument('--mod_cluster', default=0, type=int, choices=[0, 1], help='only 0 is built')
@@ -61,7 +61,7 @@ def mDetect(args):
     from deepmod_amd import _lib, detect
     mo = {k: getattr(args, k) for k in ('outLevel', 'wrkBase', 'FileID', 'outFolder', 'recursive', 'threads', 'files_per_thread',
                                          'windowsize', 'predDet', 'predpath', 'modfile', 'fnum', 'hidden', 'outputlayer', 'Base',
-                                         'mod_cluster')}
+                                         'mod_cluster', 'Ref', 'alignStr', 'SignalGroup', 'basecall_1d', 'basecall_2strand')}
     for k in ('threads', 'files_per_thread', 'windowsize', 'fnum', 'hidden'):
         non_negative(mo[k], k)
     if mo['files_per_thread'] < 2:
@@ -70,8 +70,14 @@ def mDetect(args):
         raise SystemExit('Error: --windowsize must be odd')
     if not mo['outFolder'].endswith('/'):
         mo['outFolder'] += '/'
-    mo['region'] = [[None, None, None]]
-    mo['ConUnk'] = True
+    mo['region'] = []                                    # bin/DeepMod.py:153-160: "chr:start:end;chr2:start"
+    if args.region is None or len(args.region) == 0:
+        mo['region'].append([None, None, None])
+    else:
+        for mr in args.region.split(';'):
+            mr_sp = mr.split(':')
+            mo['region'].append([mr_sp[0], int(mr_sp[1]) if len(mr_sp) > 1 else None, int(mr_sp[2]) if len(mr_sp) > 2 else None])
+    mo['ConUnk'] = args.ConUnk not in (False, 'False', 'false', '0', 0)
     errs = []
     if mo['predDet'] == 1:
         if not mo['wrkBase'] or not os.path.isdir(mo['wrkBase']):

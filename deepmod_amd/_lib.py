@@ -13,6 +13,11 @@ DM_OPT_PROFILE = 1
 DM_OPT_PRECISION = 2
 DM_PREC_F32 = 0
 DM_PREC_F16X3 = 1
+(DM_MAP_STATUS, DM_MAP_N_ROWS, DM_MAP_LEFTCLIP, DM_MAP_RIGHTCLIP, DM_MAP_EV_LO, DM_MAP_EV_HI, DM_MAP_FIRST_MATCH_POS,
+ DM_MAP_LAST_MATCH_POS, DM_MAP_NUM_INSERT, DM_MAP_NUM_DELETE, DM_MAP_NUM_MISMATCH, DM_MAP_STRAND, DM_MAP_POS_AFTER_CLIP,
+ DM_MAP_EVENTS_AFTER_CLIP) = range(14)
+DM_MAP_INFO_LEN = 16
+DM_MAP_OK, DM_MAP_NO_MATCH, DM_MAP_NEED_ROWS = 0, 1, 2
 DM_WEIGHT_FLOATS = 408402
 
 _c = ctypes
@@ -49,6 +54,10 @@ SIGNATURES = [
     ("dm_cluster_create", _vp, [_c.c_int, _vp, _c.c_size_t]),
     ("dm_cluster_destroy", None, [_vp]),
     ("dm_cluster_predict", _c.c_int, [_vp, _vp, _i64, _vp]),
+    ("dm_signal_create", _vp, [_c.c_int]),
+    ("dm_signal_destroy", None, [_vp]),
+    ("dm_map_read", _c.c_int, [_c.c_int, _i64, _c.c_char_p, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    ("dm_signal_event_stats", _c.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_i64), _vp]),
 ]
 
 

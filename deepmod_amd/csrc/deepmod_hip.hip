@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -974,3 +975,6 @@ int dm_summary_reduce_rccl(dm_summary* s, const void* unique_id128, int rank, in
 }
 
 }  // extern "C"
+
+#include "signal.hip.inc"
+#include "readmap.inc"

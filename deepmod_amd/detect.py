@@ -6,10 +6,11 @@ function names, argument meaning and side effects, driving the HIP library inste
     sum_handler      myDetect.py:1028-1120 per (chr, strand) coverage / mod-count summary -> BED
     mDetect_manager  myDetect.py:1124-1263 sharding, worker processes, index merge, .done marker
 
-What is NOT here (out of scope this round): FAST5/HDF5 reading, the aligner
-subprocess and the CIGAR walk (myDetect.py:45-782).  Workers therefore consume *feature
-containers* (deepmod_amd/predstore.py: per-read `mfeatures`, `base_map_info`, clips, event bases -
-exactly the arguments the reference hands to mPredict1 at myDetect.py:715) instead of .fast5 files.
+Inputs are containers instead of .fast5 files (no h5py / libhdf5 in this image): *raw containers*
+(deepmod_amd/rawreads.py: DAC samples + basecaller events; normalised on the GPU, aligned with the SAM
+records, mapped by dm_map_read) or *feature containers* (deepmod_amd/predstore.py: per-read `mfeatures`,
+`base_map_info`, clips, event bases - exactly the arguments the reference hands to mPredict1 at
+myDetect.py:715).
 """
 from __future__ import annotations
 
@@ -21,7 +22,7 @@ from collections import defaultdict
 
 import numpy as np
 
-from . import predstore
+from . import predstore, rawreads, readmap
 
 rnn_pred_batch_size = 512   # myDetect.py:30
 pre_base_str = 'rnn.pred.ind'  # myDetect.py:33-ish: index-file stem used by the manager and workers
@@ -122,12 +123,92 @@ def mPredict_batch(moptions, sp_options, reads):
 # ---------------------------------------------------------------------------------------------
 # worker
 # ---------------------------------------------------------------------------------------------
+def _predict_and_store(moptions, sp_options, store, good, src):
+    """mPredict1 for a group of reads (one device call), prediction tables and index entries (myDetect.py:715-718)."""
+    if not good:
+        return
+    try:      # one device call for all reads of the group (see mPredict_batch)
+        sess = sp_options['rnn'][0]
+        if hasattr(sess, 'model') and getattr(sess, 'model') is not None:
+            pred_nums = mPredict_batch(moptions, sp_options, good)
+        else:
+            pred_nums = [mPredict1(moptions, sp_options, {'f5data': {rd['readk']: (None, rd['events'], None, src)}},
+                                   rd['mfeatures'], rd['base_map_info'], rd['readk'], rd['start_clip'], rd['end_clip'])
+                         for rd in good]
+    except Exception as exc:  # same (reason -> files) error channel as the reference
+        sp_options["Error"]["Prediction failed: %s" % type(exc).__name__].append(src)
+        return
+    for rd, pred_mod_num in zip(good, pred_nums):
+        rsrc = rd.get('src', src)
+        key = store.add(rd, rd['base_map_info'], pred_mod_num, rsrc, moptions)
+        sp_options['Mod'].append([rd['chr'], rd['strand'], rd['mapped_start'], key,
+                                  os.path.relpath(rsrc, moptions['wrkBase']), store.relpath(moptions)])
+
+
+def _alignment_lines(moptions, sp_options, raw_files, f5data):
+    """SAM lines for the reads of this batch.  With the aligner binary on PATH: the reference's own call
+    (myDetect.py:396-425: FASTA of the event basecalls -> `bwa mem -x ont2d` / `minimap2 -ax map-ont`); otherwise
+    the side-car `<container>.sam` files written next to the raw containers."""
+    import shutil
+    import subprocess
+    import tempfile
+    align_str = moptions.get('alignStr', 'bwa')
+    if shutil.which(align_str) and moptions.get('Ref'):
+        with tempfile.NamedTemporaryFile(suffix='.fa', mode='w') as temp_fa, tempfile.NamedTemporaryFile() as temp_sam:
+            for f5k in sorted(f5data.keys()):
+                temp_fa.write(''.join(['>', f5k, '\n', f5data[f5k][0], '\n']))
+            temp_fa.flush()
+            if align_str == 'bwa':
+                cmd_opt = ['mem', '-x', 'ont2d', '-v', '1', '-t', '1', moptions['Ref'], temp_fa.name]
+            else:
+                cmd_opt = ['-ax', 'map-ont', moptions['Ref'], temp_fa.name]
+            if subprocess.call([align_str] + cmd_opt, stdout=temp_sam) != 0:
+                return None
+            temp_sam.seek(0)
+            return [str(ln, 'utf-8').strip() for ln in temp_sam.readlines()]
+    lines = []
+    for rf in raw_files:
+        sam = rf[:-len(rawreads.RAW_SUFFIX)] + '.sam'
+        if not os.path.isfile(sam):
+            return None
+        with open(sam) as fh:
+            lines.extend(ln.rstrip('\n') for ln in fh)
+    return lines
+
+
+def mDetect1_raw(moptions, sp_options, store, raw_files):
+    """The reference's mDetect1 for raw reads (myDetect.py:392-465): signal -> events (GPU normalisation and event
+    statistics) -> alignment records -> base_map_info + features -> prediction."""
+    f5data = rawreads.get_Event_Signals(moptions, sp_options, raw_files)
+    if not f5data:
+        return
+    align_info = _alignment_lines(moptions, sp_options, raw_files, f5data)
+    if align_info is None:
+        for f5k in sorted(f5data.keys()):
+            sp_options["Error"]["Cannot running aligment"].append(f5data[f5k][3])
+        return
+    sp_param = defaultdict()
+    sp_param['f5data'] = f5data
+    sp_param['ref_info'] = defaultdict()
+    f5align = readmap.parse_sam(moptions, sp_options, sp_param, align_info, f5data)
+    sp_param['f5status'] = ""
+    sp_param['line'] = ""
+    reads = readmap.map_records(moptions, sp_options, sp_param, f5align, f5data)
+    _predict_and_store(moptions, sp_options, store, reads, raw_files[0])
+
+
 def mDetect1(moptions, sp_options, container_files):
-    """Per-batch body of the worker (counterpart of myDetect.mDetect1 :392-465 restricted to the hot
-    path): for every read of every feature container run mPredict1, store the per-read prediction
-    table and the per-chromosome index lines."""
+    """Per-batch body of the worker (counterpart of myDetect.mDetect1 :392-465): raw containers (`.dmraw.npz`:
+    DAC samples + basecaller events, aligned here) go through the whole path, feature containers (`.dmfeat.npz`:
+    the arguments the reference hands to mPredict1) enter at the prediction step.  Per-read prediction tables and
+    the per-chromosome index lines are written as the reference does."""
     store = predstore.PredWriter(sp_options['ctfolder'], sp_options['batchid'])
+    raw_files = [cf for cf in container_files if cf.endswith(rawreads.RAW_SUFFIX)]
+    if raw_files:
+        mDetect1_raw(moptions, sp_options, store, raw_files)
     for cf in container_files:
+        if cf.endswith(rawreads.RAW_SUFFIX):
+            continue
         try:
             reads = predstore.load_feature_container(cf)
         except Exception:
@@ -139,23 +220,7 @@ def mDetect1(moptions, sp_options, container_files):
                 sp_options["Error"]["Less Event"].append(cf)
             else:
                 good.append(rd)
-        if not good:
-            continue
-        try:      # one device call for all reads of the container (see mPredict_batch)
-            sess = sp_options['rnn'][0]
-            if hasattr(sess, 'model') and getattr(sess, 'model') is not None:
-                pred_nums = mPredict_batch(moptions, sp_options, good)
-            else:
-                pred_nums = [mPredict1(moptions, sp_options, {'f5data': {rd['readk']: (None, rd['events'], None, cf)}},
-                                       rd['mfeatures'], rd['base_map_info'], rd['readk'], rd['start_clip'], rd['end_clip'])
-                             for rd in good]
-        except Exception as exc:  # same (reason -> files) error channel as the reference
-            sp_options["Error"]["Prediction failed: %s" % type(exc).__name__].append(cf)
-            continue
-        for rd, pred_mod_num in zip(good, pred_nums):
-            key = store.add(rd, rd['base_map_info'], pred_mod_num, cf, moptions)
-            sp_options['Mod'].append([rd['chr'], rd['strand'], rd['mapped_start'], key,
-                                      os.path.relpath(cf, moptions['wrkBase']), store.relpath(moptions)])
+        _predict_and_store(moptions, sp_options, store, good, cf)
     store.close()
     # index files <ctfolder>/<chr>.rnn.pred.ind.<batchid>   (myDetect.py:762-782)
     by_chr = defaultdict(list)
@@ -327,11 +392,12 @@ def mDetect_manager(moptions):
         else:
             moptions['modfile'] = [moptions['modfile'], moptions['modfile'][:moptions['modfile'].rfind('/') + 1]]
         start_time = time.time()
-        pat = '*' + predstore.CONTAINER_SUFFIX
-        f5files = glob.glob(os.path.join(moptions['wrkBase'], pat))
-        if moptions['recursive'] == 1:
-            for depth in ('*/', '*/*/', '*/*/*/'):
-                f5files.extend(glob.glob(os.path.join(moptions['wrkBase'], depth + pat)))
+        f5files = []
+        for pat in ('*' + predstore.CONTAINER_SUFFIX, '*' + rawreads.RAW_SUFFIX):
+            f5files.extend(glob.glob(os.path.join(moptions['wrkBase'], pat)))
+            if moptions['recursive'] == 1:
+                for depth in ('*/', '*/*/', '*/*/*/'):
+                    f5files.extend(glob.glob(os.path.join(moptions['wrkBase'], depth + pat)))
         f5files = sorted(f5files)
         print('Total files=%d' % len(f5files))
         os.makedirs(moptions['outFolder'] + moptions['FileID'], exist_ok=True)

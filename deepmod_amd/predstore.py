@@ -99,14 +99,19 @@ class PredWriter:
         self.arrays[key + '/readbasei'] = bmi['readbasei'].astype(np.uint64)
         self.arrays[key + '/mod_pred'] = bmi['mod_pred'].astype(np.int64)
         fwd = rd['strand'] == '+'
-        nins = int((bmi['refbase'] == '-').sum())
-        ndel = int((bmi['readbase'] == '-').sum())
-        nmis = int(((bmi['refbase'] != bmi['readbase']) & (bmi['refbase'] != '-') & (bmi['readbase'] != '-')).sum())
+        if 'num_insertions' in rd:      # counters of the CIGAR walk (myDetect.py:737-741), when the read came through it
+            nins, ndel, nmis = int(rd['num_insertions']), int(rd['num_deletions']), int(rd['num_mismatches'])
+        else:
+            nins = int((bmi['refbase'] == '-').sum())
+            ndel = int((bmi['readbase'] == '-').sum())
+            nmis = int(((bmi['refbase'] != bmi['readbase']) & (bmi['refbase'] != '-') & (bmi['readbase'] != '-')).sum())
         self.attrs[key] = {
             'mapped_chr': rd['chr'], 'mapped_strand': rd['strand'],
             'mapped_start': int(bmi['refbasei'][0] if fwd else bmi['refbasei'][-1]),
             'mapped_end': int(bmi['refbasei'][-1] if fwd else bmi['refbasei'][0]),
-            'clipped_bases_start': int(rd['start_clip']), 'clipped_bases_end': int(rd['end_clip']),
+            # myDetect.py:729-734: for '-' reads the two clips are stored the other way round
+            'clipped_bases_start': int(rd['start_clip'] if fwd else rd['end_clip']),
+            'clipped_bases_end': int(rd['end_clip'] if fwd else rd['start_clip']),
             'num_insertions': nins, 'num_deletions': ndel, 'num_mismatches': nmis,
             'num_matches': int(len(bmi) - nmis - nins - ndel),
             'pred_mod_num': int(pred_mod_num), 'f5file': src_file, 'readk': rd['readk']}

@@ -1,0 +1,112 @@
+"""Raw-read containers and the signal -> event-table stage.
+
+The reference reads one FAST5 (HDF5) per read: raw DAC samples `Raw/Reads/*/Signal` and the basecaller's event
+table `Analyses/Basecall_1D_*/BaseCalled_template/Events`.  Neither h5py nor libhdf5 exists in this image, so the
+same arrays travel in `.dmraw.npz` containers (several reads per file); everything downstream of the HDF5 read
+follows the reference:
+
+  getEvent            myDetect.py:237-251  (Albacore 2.x, SignalGroup 'simple': stay events (move == 0) are
+                                           merged into the preceding event; mean / stdv rounded to 3 decimals)
+  mnormalized + stats myDetect.py:266-282, :332-343  -> deepmod_amd.signal (GPU)
+  get_Event_Signals   myDetect.py:348-386  -> f5data[read_id] = (basecall, m_event, raw, file, (0, 0))
+
+Not built: the Albacore 1.x timing arithmetic (:163-232) and the `EventTable` re-segmentation (`SignalGroup != simple`).
+"""
+from __future__ import annotations
+
+import json
+from collections import defaultdict
+from typing import Dict, List
+
+import numpy as np
+
+from . import signal as dm_signal
+
+RAW_SUFFIX = '.dmraw.npz'
+EVENT_DTYPE = [('mean', '<f4'), ('stdv', '<f4'), ('start', np.uint64), ('length', np.uint64), ('model_state', 'U5')]
+EVENTS_DATA_DTYPE = [('mean', '<f8'), ('stdv', '<f8'), ('start', np.uint64), ('length', np.uint64),
+                     ('model_state', 'U5'), ('move', np.int64)]
+
+
+def save_raw_container(path: str, reads: List[Dict]) -> None:
+    """reads: dicts with read_id, raw (int16), events_data (EVENTS_DATA_DTYPE)."""
+    if not path.endswith(RAW_SUFFIX):
+        raise ValueError('raw containers must end with ' + RAW_SUFFIX)
+    arrays = {}
+    metas = []
+    for i, rd in enumerate(reads):
+        ed = rd['events_data']
+        arrays['r%d_raw' % i] = np.asarray(rd['raw'], dtype=np.int16)
+        for f in ('mean', 'stdv', 'start', 'length', 'model_state', 'move'):
+            arrays['r%d_ev_%s' % (i, f)] = np.asarray(ed[f])
+        metas.append({'read_id': rd['read_id']})
+    arrays['meta'] = np.array(json.dumps(metas))
+    with open(path, 'wb') as fh:
+        np.savez_compressed(fh, **arrays)
+
+
+def load_raw_container(path: str) -> List[Dict]:
+    z = np.load(path, allow_pickle=False)
+    reads = []
+    for i, m in enumerate(json.loads(str(z['meta']))):
+        n = len(z['r%d_ev_start' % i])
+        ed = np.zeros(n, dtype=EVENTS_DATA_DTYPE)
+        for f in ('mean', 'stdv', 'start', 'length', 'model_state', 'move'):
+            ed[f] = z['r%d_ev_%s' % (i, f)]
+        reads.append({'read_id': m['read_id'], 'raw': z['r%d_raw' % i], 'events_data': ed})
+    return reads
+
+
+def getEvent(moptions, sp_param):
+    """Albacore-2 'simple' branch of the reference's getEvent (myDetect.py:237-251)."""
+    events_data = sp_param['events_data']
+    if moptions.get('SignalGroup', 'simple') != 'simple':
+        raise NotImplementedError("SignalGroup %r (EventTable re-segmentation) is not built" % moptions.get('SignalGroup'))
+    n = len(events_data)
+    if n == 0:
+        sp_param['f5status'] = 'No events data'
+        return
+    move = np.asarray(events_data['move'])
+    heads = np.flatnonzero(np.r_[True, move[1:] > 0])            # an event starts where move > 0 (and at index 0)
+    seg_len = np.add.reduceat(events_data['length'].astype(np.uint64), heads)
+    m_event = np.zeros(len(heads), dtype=EVENT_DTYPE)
+    m_event['mean'] = np.round(events_data['mean'][heads], 3)
+    m_event['stdv'] = np.round(events_data['stdv'][heads], 3)
+    m_event['start'] = events_data['start'][heads]
+    m_event['length'] = seg_len
+    m_event['model_state'] = events_data['model_state'][heads]
+    sp_param['m_event'] = m_event
+    sp_param['m_event_basecall'] = ''.join([ms[2] for ms in m_event['model_state']])
+    sp_param['left_right_skip'] = (0, 0)
+
+
+def get_Event_Signals(moptions, sp_options, raw_files, normalizer=None):
+    """-> f5data {read_id: (basecall, m_event, raw_signals, file, left_right_skip)}   (myDetect.py:348-386)"""
+    f5data = {}
+    if "Error" not in sp_options:
+        sp_options["Error"] = defaultdict(list)
+    for f5f in raw_files:
+        try:
+            reads = load_raw_container(f5f)
+        except Exception:
+            sp_options["Error"]["Cannot open fast5 or other errors"].append(f5f)
+            print("Cannot open fast5 or other errors: {}".format(f5f))
+            continue
+        for rd in reads:
+            sp_param = {'mfile_path': f5f, 'f5status': '', 'raw_signals': rd['raw'], 'events_data': rd['events_data'],
+                        'read_id': rd['read_id'].replace(" ", ":::").replace("\t", "|||")}
+            try:
+                getEvent(moptions, sp_param)
+                if sp_param['f5status'] == '':
+                    dm_signal.mnormalized_event_stats(moptions, sp_param, normalizer)
+            except Exception as exc:
+                sp_param['f5status'] = "Cannot open fast5 or other errors"
+                print("Cannot open fast5 or other errors: {} ({})".format(f5f, exc))
+            if sp_param['f5status'] == '':
+                if sp_param['read_id'] in f5data:
+                    print('Duplicate id', sp_param['read_id'], f5f)
+                f5data[sp_param['read_id']] = (sp_param['m_event_basecall'], sp_param['m_event'], None, f5f,
+                                               sp_param['left_right_skip'])
+            else:
+                sp_options["Error"][sp_param['f5status']].append(f5f)
+    return f5data

@@ -1,0 +1,187 @@
+"""SAM record -> base_map_info -> features -> prediction for raw reads.
+
+Host-side mirror of the reference's `handle_line` (myDetect.py:929-943), `getRefSeq` (:472-486) and `handle_record`
+(:491-782): same names, arguments and side effects (`sp_options['Mod']`, `sp_options['Error']`).  The per-base CIGAR
+walk runs in compiled code behind `dm_map_read` (deepmod_amd/csrc/readmap.inc); `samtools faidx` is replaced by a
+plain FASTA reader (no external binaries in this image) and the HDF5 prediction file by deepmod_amd.predstore.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from collections import defaultdict
+from typing import Dict
+
+import numpy as np
+
+from . import _lib, features, predstore
+
+OUTPUT_WARNING = 1   # myCom.OUTPUT_WARNING
+
+
+def handle_line(moptions, sp_param, f5align):
+    """One SAM line -> f5align[qname] = (mapq, flag, rname, pos, cigar, seq), best mapq wins (myDetect.py:929-943)."""
+    lsp = sp_param['line'].split('\t')
+    qname, flag, rname, pos, mapq, cigar, _, _, _, seq, _ = lsp[:11]
+    if qname == '*':
+        sp_param['f5status'] = "qname is *"
+    elif int(mapq) == 255:
+        sp_param['f5status'] = "mapq is 255"
+    elif int(pos) == 0:
+        sp_param['f5status'] = "pos is 0"
+    elif cigar == '*':
+        sp_param['f5status'] = "cigar is *"
+    elif rname == '*':
+        sp_param['f5status'] = "rname is *"
+    if not sp_param['f5status'] == "":
+        return qname
+    if (qname not in f5align) or f5align[qname][0] < int(mapq):
+        f5align[qname] = (int(mapq), int(flag), rname, int(pos), cigar, seq)
+    return qname
+
+
+_fasta_cache: Dict[str, Dict[str, str]] = {}
+
+
+def read_fasta(path: str) -> Dict[str, str]:
+    """{name: upper-cased sequence}; name = first word of the header (what `samtools faidx ref name` resolves)."""
+    if path not in _fasta_cache:
+        seqs, name, parts = {}, None, []
+        with open(path) as fh:
+            for line in fh:
+                line = line.strip()
+                if line.startswith('>'):
+                    if name is not None:
+                        seqs[name] = ''.join(parts).upper()
+                    name, parts = line[1:].split()[0], []
+                elif line:
+                    parts.append(line)
+        if name is not None:
+            seqs[name] = ''.join(parts).upper()
+        _fasta_cache[path] = seqs
+    return _fasta_cache[path]
+
+
+def getRefSeq(moptions, sp_param, rname):
+    """sp_param['ref_info'][rname] = upper-cased chromosome sequence (myDetect.py:472-486)."""
+    seqs = read_fasta(moptions['Ref'])
+    if rname not in seqs:
+        print('Fatal Error!!! cannot find the chrosome sequence %s' % rname)
+    else:
+        sp_param['ref_info'][rname] = seqs[rname]
+
+
+def map_read(flag: int, pos1: int, cigar: str, readseq: str, refseq, n_events: int):
+    """dm_map_read wrapper -> dict(status, base_map_info, leftclip, rightclip, ev_lo, ev_hi, counts, ...).
+    `refseq` may be a str or an ASCII bytes object (pass bytes to avoid re-encoding a chromosome per read)."""
+    lib = _lib.load()
+    ref_b = refseq if isinstance(refseq, (bytes, bytearray)) else refseq.encode('ascii')
+    seq_b = readseq.encode('ascii')
+    info = (ctypes.c_int64 * _lib.DM_MAP_INFO_LEN)()
+    cap = len(seq_b) + 64
+    while True:
+        refb = np.empty(cap, 'S1')
+        readb = np.empty(cap, 'S1')
+        refi = np.empty(cap, np.uint64)
+        readi = np.empty(cap, np.uint64)
+        _lib.check(lib.dm_map_read(int(flag), int(pos1), cigar.encode('ascii'), seq_b, len(seq_b), ref_b, len(ref_b),
+                                   int(n_events), refb.ctypes.data, readb.ctypes.data, refi.ctypes.data, readi.ctypes.data,
+                                   cap, info))
+        if info[_lib.DM_MAP_STATUS] != _lib.DM_MAP_NEED_ROWS:
+            break
+        cap = int(info[_lib.DM_MAP_N_ROWS])
+    out = {'status': int(info[_lib.DM_MAP_STATUS]), 'strand': '-' if info[_lib.DM_MAP_STRAND] else '+',
+           'pos_after_clip': int(info[_lib.DM_MAP_POS_AFTER_CLIP]), 'events_after_clip': int(info[_lib.DM_MAP_EVENTS_AFTER_CLIP]),
+           'num_insertions': int(info[_lib.DM_MAP_NUM_INSERT]), 'num_deletions': int(info[_lib.DM_MAP_NUM_DELETE]),
+           'num_mismatches': int(info[_lib.DM_MAP_NUM_MISMATCH])}
+    if out['status'] == _lib.DM_MAP_OK:
+        n = int(info[_lib.DM_MAP_N_ROWS])
+        out['base_map_info'] = predstore.make_base_map_info(refb[:n].astype('U1'), readb[:n].astype('U1'), refi[:n], readi[:n])
+        out.update(leftclip=int(info[_lib.DM_MAP_LEFTCLIP]), rightclip=int(info[_lib.DM_MAP_RIGHTCLIP]),
+                   ev_lo=int(info[_lib.DM_MAP_EV_LO]), ev_hi=int(info[_lib.DM_MAP_EV_HI]),
+                   first_match_pos=int(info[_lib.DM_MAP_FIRST_MATCH_POS]), last_match_pos=int(info[_lib.DM_MAP_LAST_MATCH_POS]))
+    return out
+
+
+def _in_region(moptions, rname, pos=None, n_events=None):
+    for cur_mr in moptions.get('region', [[None, None, None]]):
+        if cur_mr[0] in ['', None, rname]:
+            if pos is None:
+                return True
+            if (cur_mr[1] in ['', None] or pos > cur_mr[1]) and (cur_mr[2] in ['', None] or pos + n_events < cur_mr[2]):
+                return True
+    return False
+
+
+def map_records(moptions, sp_options, sp_param, f5align, f5data):
+    """First half of handle_record (myDetect.py:491-713): alignment table, clips and feature matrix per aligned read.
+    -> list of read dicts in the form mPredict1 / mPredict_batch / PredWriter consume."""
+    reads = []
+    ref_bytes = sp_param.setdefault('ref_bytes', {})
+    for readk_ind, readk in enumerate(list(f5align.keys())):
+        sp_param['f5status'] = ""
+        sp_param['mfile_path'] = f5data[readk][3]
+        mapq, flag, rname, pos, cigar, readseq = f5align[readk]
+        if (not moptions.get('ConUnk', True)) and any(ch in rname for ch in '_-/:'):
+            continue
+        if not _in_region(moptions, rname):
+            continue
+        if rname not in sp_param['ref_info']:
+            getRefSeq(moptions, sp_param, rname)
+        if rname not in sp_param['ref_info']:
+            sp_options["Error"]["No reference sequence"].append(f5data[readk][3])
+            continue
+        if rname not in ref_bytes:
+            ref_bytes[rname] = sp_param['ref_info'][rname].encode('ascii')
+        events = f5data[readk][1]
+        try:
+            mp = map_read(flag, pos, cigar, readseq, ref_bytes[rname], len(events))
+        except _lib.DeepModHipError as exc:
+            sp_options["Error"]["CIGAR-Error: %s" % exc].append(f5data[readk][3])
+            continue
+        if not _in_region(moptions, rname, mp['pos_after_clip'], mp['events_after_clip']):
+            continue
+        if mp['status'] == _lib.DM_MAP_NO_MATCH:
+            if moptions.get('outLevel', OUTPUT_WARNING) <= OUTPUT_WARNING:
+                print("Errorfast5 " + f5data[readk][3])
+                print('match-Error!!! no first and/or last match', f5data[readk][3], str(flag), rname, str(pos))
+            continue
+        if mp['ev_hi'] - mp['ev_lo'] < 50:                                            # :702-705
+            sp_param['f5status'] = "Less Event"
+            sp_options["Error"]["Less Event"].append(f5data[readk][3])
+            continue
+        bmi = mp['base_map_info']
+        sp_param['f5data'] = f5data
+        mfeatures, isdif = features.get_Feature(moptions, sp_options, sp_param, f5align, f5data, readk, mp['leftclip'],
+                                                mp['rightclip'], bmi, mp['strand'], rname, mp['first_match_pos'],
+                                                mp['num_insertions'], mp['num_deletions'])
+        if not sp_param['f5status'] == "":
+            continue
+        reads.append({'readk': readk, 'readk_ind': readk_ind, 'chr': rname, 'strand': mp['strand'],
+                      'mapped_start': f5align[readk][3] - 1, 'start_clip': mp['leftclip'], 'end_clip': mp['rightclip'],
+                      'base_map_info': bmi, 'mfeatures': mfeatures, 'events': events, 'src': f5data[readk][3],
+                      'num_insertions': mp['num_insertions'], 'num_deletions': mp['num_deletions'],
+                      'num_mismatches': mp['num_mismatches']})
+    return reads
+
+
+def parse_sam(moptions, sp_options, sp_param, align_info, f5data):
+    """SAM text lines -> f5align; reads without a usable record go to the error channel (myDetect.py:436-457)."""
+    f5align = defaultdict()
+    f5keydict = {}
+    for line in align_info:
+        line = line.strip()
+        if len(line) == 0 or line[0] == '@':
+            continue
+        sp_param['f5status'] = ""
+        sp_param['line'] = line
+        qname = handle_line(moptions, sp_param, f5align)
+        if sp_param['f5status'] == "":
+            f5keydict[qname] = True
+    for f5k in sorted(f5data.keys()):
+        if f5k not in f5keydict:
+            sp_options["Error"]["Not in alignment sam"].append(f5data[f5k][3])
+    for qname in list(f5align.keys()):
+        if qname not in f5data:
+            del f5align[qname]
+    return f5align

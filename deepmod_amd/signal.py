@@ -1,0 +1,94 @@
+"""Raw-signal normalisation and per-event statistics on the GPU.
+
+Host-side mirror of the reference's `mnormalized` (myDetect.py:266-282) and of the per-event mean / stdv loop
+at the end of `getFast5Info` (:332-343): same `sp_param` keys in, same fields of `sp_param['m_event']` updated.
+The arithmetic runs in libdeepmod_hip.so (deepmod_amd/csrc/signal.hip.inc); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+
+class SignalNormalizer:
+    """One dm_signal handle (device buffers + stream) on one GPU; reuse it across reads."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        self._h = self._lib.dm_signal_create(device)
+        if not self._h:
+            raise _lib.DeepModHipError("dm_signal_create: " + _lib.last_error())
+
+    def close(self):
+        if self._h:
+            self._lib.dm_signal_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def event_stats(self, raw, ev_start, ev_length, want_signal: bool = False):
+        """raw int16[n]; ev_start/ev_length uint64[E] -> (mean f32[E], stdv f32[E], norm dict, first_empty, signal|None)"""
+        raw = np.ascontiguousarray(raw)
+        if raw.dtype != np.int16:
+            if not np.issubdtype(raw.dtype, np.integer) or raw.size and (raw.min() < -32768 or raw.max() > 32767):
+                raise ValueError("raw signal must hold int16 DAC values (FAST5 Raw/Reads/*/Signal)")
+            raw = raw.astype(np.int16)
+        st = np.ascontiguousarray(ev_start, dtype=np.uint64)
+        ln = np.ascontiguousarray(ev_length, dtype=np.uint64)
+        n_ev = len(st)
+        mean = np.empty(n_ev, np.float32)
+        stdv = np.empty(n_ev, np.float32)
+        norm6 = np.empty(6, np.float64)
+        first_empty = ctypes.c_int64(0)
+        sig = np.empty(len(raw), np.float64) if want_signal else None
+        _lib.check(self._lib.dm_signal_event_stats(
+            self._h, raw.ctypes.data, len(raw), st.ctypes.data, ln.ctypes.data, n_ev, mean.ctypes.data, stdv.ctypes.data,
+            norm6.ctypes.data, ctypes.byref(first_empty), sig.ctypes.data if want_signal else None))
+        norm = dict(zip(("mshift", "mscale", "read_med", "read_mad", "lower_lim", "upper_lim"), norm6.tolist()))
+        return mean, stdv, norm, int(first_empty.value), sig
+
+
+_default: Optional[SignalNormalizer] = None
+
+
+def mnormalized_event_stats(moptions, sp_param, normalizer: Optional[SignalNormalizer] = None, want_signal: bool = False):
+    """`mnormalized(moptions, sp_param)` followed by the per-event statistics loop of `getFast5Info`
+    (myDetect.py:266-282 + :332-343) in one device pass.
+
+    In : sp_param['raw_signals'] int16[n], sp_param['m_event'] (start, length filled; mean, stdv overwritten).
+    Out: sp_param['m_event']['mean'|'stdv'] (float32, rounded to 3 decimals), sp_param['norm'] (the four medians and
+         the clip limits), sp_param['raw_signals'] replaced by the normalised float64 signal when want_signal.
+    The reference's handling of an event whose slice is empty is kept: the loop stops there; if that is event i > 500
+    the table is truncated to m_event[:i-1], otherwise it is left as is (myDetect.py:337-340; the status assignment on
+    :340 is a comparison and has no effect)."""
+    global _default
+    if normalizer is None:
+        if _default is None:
+            _default = SignalNormalizer(int(moptions.get('device', 0)) if hasattr(moptions, 'get') else 0)
+        normalizer = _default
+    ev = sp_param['m_event']
+    if not ev['start'][0] < (ev['start'][-1] + ev['length'][-1]):
+        print('Fatal error signal start position is less than the end position', sp_param.get('mfile_path'),
+              ev['start'][0], ev['start'][-1], ev['length'][-1])
+    mean, stdv, norm, first_empty, sig = normalizer.event_stats(sp_param['raw_signals'], ev['start'], ev['length'], want_signal)
+    n_ok = first_empty
+    ev['mean'][:n_ok] = mean[:n_ok]
+    ev['stdv'][:n_ok] = stdv[:n_ok]
+    if first_empty < len(ev):
+        i = first_empty
+        print('Signal out of range {}: {}-{} {};{} for {}'.format(i, ev['start'][i], ev['length'][i], len(ev),
+                                                                  len(sp_param['raw_signals']), sp_param.get('mfile_path')))
+        if i > 500:
+            sp_param['m_event'] = ev[:i - 1]
+    sp_param['norm'] = norm
+    if want_signal:
+        sp_param['raw_signals'] = sig
+    return sp_param

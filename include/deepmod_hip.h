@@ -149,6 +149,58 @@ dm_cluster* dm_cluster_create(int device, const float* weights, size_t n_floats)
 void dm_cluster_destroy(dm_cluster* c);
 int dm_cluster_predict(dm_cluster* c, const float* x, int64_t n, float* out);
 
+/* ---- raw-signal normalisation + per-event statistics ------------------------------------
+ * Replaces myDetect.py:266-282 (mnormalized: median / MAD shift-scale over the event-covered slice, second
+ * median / MAD, clip to +-5 MAD, round to 3 decimals) and :332-343 (per-event round(np.mean, 3), round(np.std, 3)
+ * into the '<f4' fields of m_event).  Results are bit-identical to numpy's (same float64 operations in the same
+ * order, including np.add.reduce's 8,192-element buffers and 8-lane pairwise sums).
+ *   raw        int16 DAC samples [n_raw] (FAST5 Raw/Reads/.../Signal), host or device (device: 16-byte aligned)
+ *   ev_start / ev_length  uint64 [n_events] host arrays (m_event['start'], m_event['length'])
+ *   ev_mean / ev_stdv     float [n_events] host outputs; NaN for an event whose slice is empty
+ *   norm6      optional double[6]: mshift, mscale, read_med, read_mad, lower_lim, upper_lim
+ *   first_empty optional: index of the first event with an empty slice (the reference stops its loop there,
+ *              :334-340), n_events if none
+ *   normalized optional double [n_raw] (host or device): the normalised signal itself */
+typedef struct dm_signal dm_signal;
+dm_signal* dm_signal_create(int device);
+void dm_signal_destroy(dm_signal* s);
+int dm_signal_event_stats(dm_signal* s, const int16_t* raw, int64_t n_raw, const uint64_t* ev_start,
+                          const uint64_t* ev_length, int64_t n_events, float* ev_mean, float* ev_stdv, double* norm6,
+                          int64_t* first_empty, double* normalized);
+
+/* ---- SAM record -> per-base alignment table (host code, no GPU needed) ---------------------
+ * Replaces the alignment walk of handle_record, myDetect.py:515-714: clip stripping, one row per M/I/D/N/=/X
+ * position, first/last-match trimming of table and event slice, '-' strand flip + complement, the CpG gap swap.
+ *   flag, pos1, cigar, readseq     fields 2, 4, 6, 10 of the SAM line (pos1 is 1-based)
+ *   refseq                         the whole (upper-cased) reference sequence of RNAME
+ *   n_events                       len(f5data[readk][1]) (events of the read, one per basecalled base)
+ *   refbase/readbase/refbasei/readbasei   caller-allocated columns of base_map_info (dtype :660), cap_rows rows
+ *   info[DM_MAP_INFO_LEN]          see DM_MAP_* below
+ * Returns 0 and info[DM_MAP_STATUS] = DM_MAP_OK | DM_MAP_NO_MATCH (read skipped, :617-622) | DM_MAP_NEED_ROWS
+ * (cap_rows < info[DM_MAP_N_ROWS]; nothing written), or a negative code for a CIGAR that is malformed or runs
+ * past the read / reference (the reference raises IndexError there). */
+#define DM_MAP_INFO_LEN 16
+#define DM_MAP_STATUS 0
+#define DM_MAP_N_ROWS 1
+#define DM_MAP_LEFTCLIP 2            /* after the strand swap of :667 = start_clip of get_Feature / mPredict1 */
+#define DM_MAP_RIGHTCLIP 3           /* = end_clip */
+#define DM_MAP_EV_LO 4               /* m_event = events[EV_LO:EV_HI] after both trimming steps */
+#define DM_MAP_EV_HI 5
+#define DM_MAP_FIRST_MATCH_POS 6
+#define DM_MAP_LAST_MATCH_POS 7
+#define DM_MAP_NUM_INSERT 8
+#define DM_MAP_NUM_DELETE 9
+#define DM_MAP_NUM_MISMATCH 10
+#define DM_MAP_STRAND 11             /* 0 '+', 1 '-' */
+#define DM_MAP_POS_AFTER_CLIP 12     /* 0-based position after the left clip (region filter of :544-553) */
+#define DM_MAP_EVENTS_AFTER_CLIP 13  /* len(m_event) at that point */
+#define DM_MAP_OK 0
+#define DM_MAP_NO_MATCH 1
+#define DM_MAP_NEED_ROWS 2
+int dm_map_read(int flag, int64_t pos1, const char* cigar, const char* readseq, int64_t readseq_len,
+                const char* refseq, int64_t refseq_len, int64_t n_events, char* refbase, char* readbase,
+                uint64_t* refbasei, uint64_t* readbasei, int64_t cap_rows, int64_t* info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,3 +128,20 @@ def test_pred_store_roundtrip(tmp_path):
     assert (c, s) == ('chrS', '-')
     for f in ('refbase', 'readbase', 'refbasei', 'mod_pred'):
         assert np.array_equal(m_pred[f], bmi[f])
+
+
+def test_sum_chr_mod_matches_reference_tool(tmp_path):
+    """BED merge across runs == output of the reference's DeepMod_tools/sum_chr_mod.py (tests/golden/make_golden_merge.py)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import GOLDEN, ROOT
+    g = json.load(open(os.path.join(GOLDEN, "merge_case.json")))
+    for rel, text in g['inputs'].items():
+        p = tmp_path / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_text(text)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "DeepMod_tools", "sum_chr_mod.py"), str(tmp_path)] + g['argv'],
+                          stdout=subprocess.DEVNULL)
+    for fn, text in g['outputs'].items():
+        assert (tmp_path / fn).read_text() == text, fn

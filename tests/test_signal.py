@@ -1,0 +1,122 @@
+"""Raw-signal normalisation + per-event statistics (reference myDetect.py:266-282, :332-343).
+
+CPU: the numpy oracle against the golden vectors produced by the reference's own functions.
+GPU: the HIP path (through the C ABI) against the goldens and against the oracle on larger seeded inputs —
+bit-exact: the outputs are float32 roundings of float64 values computed in numpy's own operation order."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import signal_oracle
+
+CASES = ['typical', 'even_slice', 'long_events', 'mid_events', 'outliers', 'clamped_tail', 'empty_late', 'empty_early']
+EVENT_DTYPE = [("mean", "<f4"), ("stdv", "<f4"), ("start", np.uint64), ("length", np.uint64), ("model_state", "U5")]
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "host_signal.npz"))
+
+
+def _events(g, name):
+    ev = np.zeros(len(g[name + '.start']), dtype=EVENT_DTYPE)
+    ev['start'] = g[name + '.start']
+    ev['length'] = g[name + '.length']
+    return ev
+
+
+def _apply_reference_rule(ev, mean, stdv, first_empty):
+    """what the reference's loop leaves behind (myDetect.py:332-343)"""
+    ev = ev.copy()
+    ev['mean'][:first_empty] = mean[:first_empty]
+    ev['stdv'][:first_empty] = stdv[:first_empty]
+    if first_empty < len(ev) and first_empty > 500:
+        ev = ev[:first_empty - 1]
+    return ev
+
+
+def _same_f32(a, b):
+    return np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_golden(golden, name):
+    raw = golden[name + '.raw']
+    ev = _events(golden, name)
+    sig, norm = signal_oracle.mnormalized(raw, ev)
+    mean, stdv, first_empty = signal_oracle.event_stats(sig, ev)
+    out = _apply_reference_rule(ev, mean, stdv, first_empty)
+    assert len(out) == int(golden[name + '.n_kept'])
+    assert _same_f32(out['mean'], golden[name + '.mean'])
+    assert _same_f32(out['stdv'], golden[name + '.stdv'])
+    if name + '.signal' in golden:
+        assert np.array_equal(sig, golden[name + '.signal'])
+
+
+def _random_case(seed, n_raw, mean_len, loc=480.0, scale=70.0):
+    rng = np.random.default_rng(seed)
+    raw = np.clip(np.round(rng.normal(loc, scale, n_raw)), -32768, 32767).astype(np.int16)
+    raw[rng.integers(0, n_raw, n_raw // 500)] = rng.integers(-32768, 32767, n_raw // 500)
+    lens = rng.geometric(1.0 / mean_len, int(n_raw / mean_len * 1.2)).astype(np.uint64)
+    first = int(rng.integers(0, 200))
+    start = (first + np.concatenate([[0], np.cumsum(lens[:-1])])).astype(np.uint64)
+    keep = (start + lens) <= n_raw - 3
+    return raw, start[keep], lens[keep]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_matches_reference_golden(golden, name):
+    from deepmod_amd import signal
+    sp = {'raw_signals': golden[name + '.raw'], 'm_event': _events(golden, name), 'mfile_path': name}
+    signal.mnormalized_event_stats({}, sp, want_signal=True)
+    ev = sp['m_event']
+    assert len(ev) == int(golden[name + '.n_kept'])
+    assert _same_f32(ev['mean'], golden[name + '.mean'])
+    assert _same_f32(ev['stdv'], golden[name + '.stdv'])
+    if name + '.signal' in golden:
+        assert np.array_equal(sp['raw_signals'], golden[name + '.signal'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_raw,mean_len", [(1, 200_000, 9.0), (2, 1_000_003, 10.0), (3, 400_000, 300.0),
+                                                 (4, 65_536, 2.0), (5, 300_000, 20000.0)])
+def test_hip_matches_oracle_bit_exact(seed, n_raw, mean_len):
+    from deepmod_amd import signal
+    raw, start, length = _random_case(seed, n_raw, mean_len)
+    ev = np.zeros(len(start), dtype=EVENT_DTYPE)
+    ev['start'], ev['length'] = start, length
+    sig, norm = signal_oracle.mnormalized(raw, ev)
+    mean, stdv, first_empty = signal_oracle.event_stats(sig, ev)
+    nz = signal.SignalNormalizer(0)
+    hmean, hstdv, hnorm, hfirst, hsig = nz.event_stats(raw, start, length, want_signal=True)
+    nz.close()
+    assert hfirst == first_empty == len(ev)
+    for k in norm:
+        assert hnorm[k] == norm[k], (k, hnorm[k], norm[k])
+    assert np.array_equal(hsig, sig)
+    assert _same_f32(hmean, mean)
+    assert _same_f32(hstdv, stdv)
+
+
+@pytest.mark.gpu
+def test_hip_device_resident_signal_and_errors():
+    from deepmod_amd import _lib, model, signal
+    raw, start, length = _random_case(9, 50_000, 8.0)
+    nz = signal.SignalNormalizer(0)
+    m0, s0, n0, f0, _ = nz.event_stats(raw, start, length)
+    d_raw = model.DeviceArray.from_host(raw, 0)                       # same call on a device-resident signal
+    mean = np.empty(len(start), np.float32)
+    stdv = np.empty(len(start), np.float32)
+    lib = _lib.load()
+    _lib.check(lib.dm_signal_event_stats(nz._h, d_raw.ptr, len(raw), start.ctypes.data, length.ctypes.data, len(start),
+                                         mean.ctypes.data, stdv.ctypes.data, None, None, None))
+    assert _same_f32(mean, m0) and _same_f32(stdv, s0)
+    with pytest.raises(_lib.DeepModHipError):                          # events that cover no signal
+        nz.event_stats(raw, start + np.uint64(10 ** 7), length)
+    with pytest.raises(ValueError):
+        nz.event_stats(raw.astype(np.float32), start, length)
+    d_raw.free()
+    nz.close()

@@ -86,3 +86,95 @@ def write_synthetic_run(out_dir: str, n_reads: int = 100, reads_per_file: int = 
             files.append(path)
             batch = []
     return files
+
+
+# ---------------------------------------------------------------------------------------------
+# raw reads: DAC samples + basecaller event table + truth SAM + FASTA (inputs of the whole path)
+# ---------------------------------------------------------------------------------------------
+def _revcomp(s: str) -> str:
+    return ''.join(_COMP[c] for c in reversed(s))
+
+
+def synthetic_raw_read(rng, genome: str, chrom: str, read_id: str, min_len=400, max_len=1500, p_sub=0.06, p_ins=0.02,
+                       p_del=0.02, max_clip=12, p_stay=0.25) -> Dict:
+    """-> {'read_id', 'raw' int16, 'events_data', 'sam' line}: a truth alignment with substitutions / indels / soft
+    clips on either strand; one basecaller event (plus `stay` continuation events, move == 0) per read base; the raw
+    signal is 520 + 75 * (level of the base + noise) DAC counts with ~8 samples per event."""
+    strand = '+' if rng.random() < 0.5 else '-'
+    span = int(rng.integers(min_len, max_len + 1))
+    start = int(rng.integers(0, len(genome) - span - 1))
+    seq, cig = [], []
+
+    def push(op, n=1):
+        if cig and cig[-1][0] == op:
+            cig[-1][1] += n
+        else:
+            cig.append([op, n])
+    pos = start
+    while pos < start + span:
+        interior = start + 2 < pos < start + span - 3
+        u = rng.random()
+        if interior and u < p_ins:
+            seq.append(str(rng.choice(list('ACGT'))))
+            push('I')
+            continue
+        if interior and u < p_ins + p_del:
+            pos += 1
+            push('D')
+            continue
+        b = genome[pos]
+        if interior and rng.random() < p_sub:
+            b = str(rng.choice([x for x in 'ACGT' if x != genome[pos]]))
+        seq.append(b)
+        push('M')
+        pos += 1
+    lead, tail = int(rng.integers(0, max_clip + 1)), int(rng.integers(0, max_clip + 1))
+    samseq = ''.join(rng.choice(list('ACGT'), lead)) + ''.join(seq) + ''.join(rng.choice(list('ACGT'), tail))
+    cigar = ('%dS' % lead if lead else '') + ''.join('%d%s' % (n, op) for op, n in cig) + ('%dS' % tail if tail else '')
+    basecall = samseq if strand == '+' else _revcomp(samseq)
+    # events and raw signal in sequencing orientation
+    from . import rawreads
+    ev_rows, chunks = [], []
+    cursor = int(rng.integers(20, 200))
+    chunks.append(np.round(520 + 75 * rng.normal(0, 1.0, cursor)))
+    for b in basecall:
+        n_sub = 1 + int(rng.random() < p_stay) + int(rng.random() < p_stay * 0.3)
+        for k in range(n_sub):
+            ln = int(rng.geometric(0.2)) + 1
+            lvl = rng.normal(_MU[b], 0.3, ln)
+            chunks.append(np.round(520 + 75 * lvl))
+            ev_rows.append((float(lvl.mean()), float(lvl.std()), cursor, ln, 'NN' + b + 'NN', 1 if k == 0 else 0))
+            cursor += ln
+    chunks.append(np.round(520 + 75 * rng.normal(0, 1.0, int(rng.integers(5, 60)))))
+    raw = np.clip(np.concatenate(chunks), -32768, 32767).astype(np.int16)
+    events_data = np.array(ev_rows, dtype=rawreads.EVENTS_DATA_DTYPE)
+    sam = '\t'.join([read_id, '0' if strand == '+' else '16', chrom, str(start + 1), '60', cigar, '*', '0', '0', samseq, '*'])
+    return {'read_id': read_id, 'raw': raw, 'events_data': events_data, 'sam': sam}
+
+
+def write_synthetic_raw_run(out_dir: str, n_reads: int = 40, reads_per_file: int = 5, genome_len: int = 30000, seed: int = 1,
+                            chrom: str = 'NC_000913.3', **read_kw):
+    """Raw containers + side-car SAM files + genome FASTA.  -> (container paths, fasta path)"""
+    from . import rawreads
+    os.makedirs(out_dir, exist_ok=True)
+    genome = synthetic_genome(genome_len, seed)
+    fasta = os.path.join(out_dir, 'genome.fa')
+    with open(fasta, 'w') as fh:
+        fh.write('>%s synthetic\n' % chrom)
+        for i in range(0, len(genome), 60):
+            fh.write(genome[i:i + 60].lower() if (i // 60) % 7 == 3 else genome[i:i + 60])   # soft-masked stretches: upper-cased on load
+            fh.write('\n')
+    rng = np.random.default_rng(seed + 11)
+    files, batch = [], []
+    for i in range(n_reads):
+        batch.append(synthetic_raw_read(rng, genome, chrom, 'rawread_%05d' % i, **read_kw))
+        if len(batch) == reads_per_file or i == n_reads - 1:
+            stem = os.path.join(out_dir, 'raw_%04d' % len(files))
+            rawreads.save_raw_container(stem + rawreads.RAW_SUFFIX, batch)
+            with open(stem + '.sam', 'w') as fh:
+                fh.write('@SQ\tSN:%s\tLN:%d\n' % (chrom, len(genome)))
+                for rd in batch:
+                    fh.write(rd['sam'] + '\n')
+            files.append(stem + rawreads.RAW_SUFFIX)
+            batch = []
+    return files, fasta

@@ -63,3 +63,40 @@ def sum_handler_oracle(chrom, strand, base, reads):
                              str(pk[2]), str(pk[2] + 1), '0,0,0', str(cov),
                              ('%d' % (100 * mod / (cov if cov > 0 else 1))), str(mod), '\n']))
     return ''.join(out).encode('ascii')
+
+
+def get_feature_oracle(ev_mean, ev_stdv, ev_length, ev_bases, refbase, readbase, refbasei, start_clip, end_clip, strand,
+                       mapped_start_pos, num_insertions):
+    """Loop-level restatement of the reference's get_Feature for fnum = 7
+    (/root/reference/bin/DeepMod_scripts/myDetect.py:839-903).  -> (mfeatures float64[rows, 10], mismatch flag).
+    PARITY PIN: tests/golden/host_getfeature.npz (tests/test_features.py)."""
+    import numpy as np
+    nev = len(ev_bases)
+    mfeatures = np.zeros((nev - end_clip + 100 - (start_clip - 100), 10))                 # :850-851
+    align_ref_pos = mapped_start_pos if strand == '+' else mapped_start_pos + len(refbase) - num_insertions - 1   # :843-846
+    aligni = 0
+    isdif = False
+    for ie in range(start_clip - 100, nev - end_clip + 100):                              # :855
+        row = ie - (start_clip - 100)
+        cur_base = ''
+        if start_clip <= ie < nev - end_clip:                                             # :857
+            while readbase[aligni] == '-':                                                # :861-867
+                if refbase[aligni] != '-':
+                    align_ref_pos += 1 if strand == '+' else -1
+                aligni += 1
+            if readbase[aligni] != ev_bases[ie]:                                          # :868-874
+                if aligni > 50:
+                    break
+                isdif = True
+            mfeatures[row][0] = align_ref_pos                                             # :875
+            cur_base = refbase[aligni]
+            if refbase[aligni] != '-':                                                    # :879-881
+                align_ref_pos += 1 if strand == '+' else -1
+            aligni += 1
+        if 0 <= ie < nev:                                                                 # :892-900
+            if cur_base in 'ACGT' and cur_base != '':
+                mfeatures[row][3 + 'ACGT'.index(cur_base)] = 1
+            mfeatures[row][7] = ev_mean[ie]
+            mfeatures[row][8] = ev_stdv[ie]
+            mfeatures[row][9] = ev_length[ie]
+    return mfeatures, isdif

@@ -27,3 +27,16 @@ def test_get_feature_matches_reference(k):
     want = G['g%d_mfeatures' % k]
     assert mf.shape == want.shape
     assert np.array_equal(mf, want)
+
+
+@pytest.mark.parametrize('k', range(int(G['n_cases'])))
+def test_get_feature_oracle_matches_reference(k):
+    from oracle import detect_oracle
+    sc, ec = [int(v) for v in G['g%d_clips' % k]]
+    nins, ndel = [int(v) for v in G['g%d_indels' % k]]
+    mf, isdif = detect_oracle.get_feature_oracle(
+        G['g%d_ev_mean' % k], G['g%d_ev_stdv' % k], G['g%d_ev_length' % k], [s[2] for s in G['g%d_model_state' % k]],
+        list(G['g%d_bmi_refbase' % k]), list(G['g%d_bmi_readbase' % k]), G['g%d_bmi_refbasei' % k], sc, ec,
+        str(G['g%d_strand' % k]), int(G['g%d_mapped_start' % k]), nins)
+    assert not isdif
+    assert np.array_equal(mf, G['g%d_mfeatures' % k])

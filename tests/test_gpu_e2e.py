@@ -71,3 +71,74 @@ def test_detect_cli_matches_oracle_pipeline(tmp_path, gpu_device):
     for strand, reads in by_strand.items():
         assert open('%s/run1/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read() == \
             detect_oracle.sum_handler_oracle('chrS', strand, 'C', reads)
+
+
+def test_detect_cli_on_raw_containers_matches_oracle_pipeline(tmp_path, gpu_device):
+    """The whole path from DAC samples: GPU signal normalisation + event statistics, SAM records through
+    dm_map_read, features, BiLSTM, summary — against the oracle chain (numpy signal oracle, Python alignment-walk
+    restatement, loop-level get_Feature / mPredict1 / sum_handler restatements, C classifier)."""
+    from deepmod_amd import rawreads, readmap
+    from oracle import readmap_oracle, signal_oracle
+    wrk = tmp_path / 'raw'
+    files, fasta = synth_reads.write_synthetic_raw_run(str(wrk), n_reads=18, reads_per_file=4, genome_len=20000, seed=5,
+                                                       chrom='chrS')
+    prefix = str(tmp_path / 'model' / 'mod_train_synth')
+    os.makedirs(os.path.dirname(prefix))
+    w = synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)   # min|p1-0.5| = 2.2e-4, 51 % class 1 on this read set
+    out = str(tmp_path / 'out')
+    cmd = [sys.executable, os.path.join(ROOT, 'bin', 'DeepMod.py'), 'detect', '--wrkBase', str(wrk), '--modfile', prefix,
+           '--Ref', fasta, '--outFolder', out, '--FileID', 'raw1', '--threads', '2', '--files_per_thread', '2', '--Base', 'C',
+           '--gpus', '1', '--alignStr', 'minimap2']
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    assert os.path.exists(out + '/raw1.done')
+
+    genome = readmap.read_fasta(fasta)['chrS']
+    classify = lambda x: oracle_np.predict_windows_c(w, np.asarray(x, np.float32))[1]
+    by_strand = {'+': [], '-': []}
+    n_reads = 0
+    min_margin = 1.0
+    for f in files:
+        sam = {ln.split('\t')[0]: ln.rstrip('\n').split('\t') for ln in open(f[:-len(rawreads.RAW_SUFFIX)] + '.sam') if not ln.startswith('@')}
+        for rd in rawreads.load_raw_container(f):
+            ed = rd['events_data']
+            # getEvent restated as the reference's loop (myDetect.py:237-251)
+            rows, pre_i, pre_len = [], 0, int(ed['length'][0])
+            for cur_i in range(1, len(ed)):
+                if ed['move'][cur_i] > 0:
+                    rows.append((int(ed['start'][pre_i]), pre_len, ed['model_state'][pre_i]))
+                    pre_i, pre_len = cur_i, int(ed['length'][cur_i])
+                else:
+                    pre_len += int(ed['length'][cur_i])
+            rows.append((int(ed['start'][pre_i]), pre_len, ed['model_state'][pre_i]))
+            ev = np.zeros(len(rows), dtype=rawreads.EVENT_DTYPE)
+            ev['start'] = [r[0] for r in rows]
+            ev['length'] = [r[1] for r in rows]
+            ev['model_state'] = [r[2] for r in rows]
+            sig, _ = signal_oracle.mnormalized(rd['raw'], ev)
+            mean, stdv, first_empty = signal_oracle.event_stats(sig, ev)
+            assert first_empty == len(ev)
+            s = sam[rd['read_id']]
+            o = readmap_oracle.map_read(int(s[1]), int(s[3]), s[5], s[9], genome, len(ev))
+            assert o['status'] == 'ok' and o['n_ev'] >= 50
+            refb = [r[0] for r in o['rows']]
+            readb = [r[1] for r in o['rows']]
+            ev_bases = [ms[2] for ms in ev['model_state']]
+            mf, isdif = detect_oracle.get_feature_oracle(mean, stdv, ev['length'], ev_bases, refb, readb, None, o['leftclip'],
+                                                         o['rightclip'], o['strand'], o['first_match_pos'], o['num_insertions'])
+            assert not isdif
+            n = len(ev) - o['leftclip'] - o['rightclip']
+            win = np.stack([mf[100 + i - 10:100 + i + 11, 3:] for i in range(n)]).astype(np.float32)
+            prob = oracle_np.predict_windows_c(w, win)[0]
+            min_margin = min(min_margin, float(np.abs(prob[:, 1] - 0.5).min()))
+            _, _, mod_pred = detect_oracle.mpredict1_oracle(mf, readb, ev_bases, o['leftclip'], o['rightclip'], classify)
+            by_strand[o['strand']].append({'refbase': ''.join(refb), 'readbase': ''.join(readb),
+                                           'refbasei': [int(r[2]) for r in o['rows']], 'mod_pred': mod_pred.tolist()})
+            n_reads += 1
+    assert n_reads == 18
+    assert min_margin > 1e-4, 'synthetic set has a near-tie window (%.2e); pick another seed' % min_margin
+    for strand, reads in by_strand.items():
+        want = detect_oracle.sum_handler_oracle('chrS', strand, 'C', reads)
+        got = open('%s/raw1/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read()
+        assert got == want
+        assert len(got) > 500

@@ -15,7 +15,11 @@
 
 #include "../../include/deepmod_hip.h"
 #include "lstm_f32.hip.inc"
+#ifdef DM16_NSPLIT      // experimental layout (the two waves of a SIMD share two M-tiles and split the N-tiles; A operands
+#include "lstm_f16_nsplit.hip.inc"   // fetched per k-step): parity-clean, 2.22 ms vs 2.03 ms per launch in round 1 - see profiles/r01
+#else
 #include "lstm_f16.hip.inc"
+#endif
 
 namespace {
 
@@ -137,10 +141,9 @@ Packed16 pack_weights_f16(const float* flat) {
             const float* kern = p;
             const float* bias = p + size_t(kin + HID) * 400;
             p += size_t(kin + HID) * 400 + 400;
-            static const int order12[7] = {4, 5, 6, 3, 0, 1, 2};
             const int own_k0 = l == 0 ? 0 : 8 * KG_H;     // k index of own hidden unit 0; unit slot 100 carries the constant 1.0
             for (int i = 0; i < nks; ++i) {
-                const int ks = l == 0 ? i : order12[i];
+                const int ks = l == 0 ? ks_at<true>(i) : ks_at<false>(i);     // stream position -> k-step
                 _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + size_t(d * KS_DIR + ks_base + i) * KSTEP_BYTES);
                 for (int t = 0; t < NT; ++t)
                     for (int lane = 0; lane < 64; ++lane)

@@ -68,6 +68,21 @@ def test_vs_oracle_ragged_sizes(n, scale, models):
     _check(prob, cls, ref_prob, ref_cls)
 
 
+def test_auc_against_oracle_classes_and_run_to_run_determinism(models):
+    """AUC of the build's p1 against the oracle's class on the same windows (1.0 when no window is a near
+    tie), and bit-identical outputs when the same batch is classified twice."""
+    from sklearn.metrics import roc_auc_score
+    w, m = models(26, 4.0)                       # this seed gives a ~50/50 class mix on synthetic windows
+    x = synth.synthetic_windows(6000, seed=77)
+    ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
+    prob, cls = m.predict_windows(x)
+    prob2, cls2 = m.predict_windows(x)
+    assert np.array_equal(prob.view(np.uint32), prob2.view(np.uint32)) and np.array_equal(cls, cls2)
+    assert 0.05 < ref_cls.mean() < 0.95
+    clear = np.abs(ref_prob[:, 1] - 0.5) > 1e-4
+    assert roc_auc_score(ref_cls[clear], prob[clear, 1]) == 1.0
+
+
 def test_empty_batch(models):
     _, m = models(21, 1.0)
     prob, cls = m.predict_windows(np.zeros((0, 21, 7), np.float32))

@@ -145,3 +145,18 @@ def test_sum_chr_mod_matches_reference_tool(tmp_path):
                           stdout=subprocess.DEVNULL)
     for fn, text in g['outputs'].items():
         assert (tmp_path / fn).read_text() == text, fn
+
+
+def test_generate_motif_pos_matches_reference_tool(tmp_path):
+    """na_/motif_ position files == output of the reference's DeepMod_tools/generate_motif_pos.py."""
+    import json
+    import subprocess
+    import sys
+    from conftest import GOLDEN, ROOT
+    g = json.load(open(os.path.join(GOLDEN, "motif_case.json")))
+    (tmp_path / "g.fa").write_text(g['fasta'])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "DeepMod_tools", "generate_motif_pos.py"), str(tmp_path / "g.fa"),
+                           str(tmp_path / "out")] + g['argv'], stdout=subprocess.DEVNULL)
+    assert sorted(os.listdir(tmp_path / "out")) == sorted(g['outputs'])
+    for fn, text in g['outputs'].items():
+        assert (tmp_path / "out" / fn).read_text() == text, fn

@@ -125,8 +125,8 @@ def extras(m, _lib, model, precision, x_dev0, x_host0, prob_dev, cls_dev, reps=4
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=sorted(PRECISIONS), default="f16x3",
                     help="MFMA mode of the classifier kernel (both meet the 1e-4 probability tolerance)")

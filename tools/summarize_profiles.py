@@ -3,12 +3,12 @@ import collections, csv, glob, json, os, shutil, sys
 tag, dest = sys.argv[1], sys.argv[2]
 src = os.path.join("gpurun_out", "prof_" + tag)
 os.makedirs(dest, exist_ok=True)
-stats = glob.glob(src + "/kt/*/*_kernel_stats.csv")
+stats = sorted(glob.glob(src + "/kt/*/*_kernel_stats.csv"), key=os.path.getmtime)
 if stats:
-    shutil.copy(stats[0], os.path.join(dest, "kernel_stats.csv"))
+    shutil.copy(stats[-1], os.path.join(dest, "kernel_stats.csv"))
 out = {}
 for d in sorted(glob.glob(src + "/pmc_*")):
-    files = glob.glob(d + "/*/*_counter_collection.csv")
+    files = sorted(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime, reverse=True)   # newest run first
     if not files:
         continue
     acc = collections.defaultdict(list)

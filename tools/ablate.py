@@ -14,12 +14,8 @@ VARIANTS = {
     "noseq": ["-DDM_ABL_NOSEQ"],
     "nobar": ["-DDM_ABL_NOBAR"],
     "nodma": ["-DDM_ABL_NODMA"],
-    "dmalow": ["-DDM16_DMA_HALF=1"], "dmahigh": ["-DDM16_DMA_HALF=2"], "dmalowtrace": ["-DDM16_DMA_HALF=1", "-DDM_TRACE"],
     "noldsb": ["-DDM16_ABL_NOLDSB"], "nodma16": ["-DDM16_ABL_NODMA"], "noldsb_nodma": ["-DDM16_ABL_NOLDSB", "-DDM16_ABL_NODMA"],
     "nsplit": ["-DDM16_NSPLIT"], "nsplit_timing": ["-DDM16_NSPLIT", "-DDM_TIMING"], "nsplit_trace": ["-DDM16_NSPLIT", "-DDM_TRACE"],
-    "epiprio": ["-DDM16_EPI_PRIO=0"], "epiprio1": ["-DDM16_EPI_PRIO=1"], "epiprioB": ["-DDM16_EPI_PRIO_B"], "epiprioBtrace": ["-DDM16_EPI_PRIO_B", "-DDM_TRACE"],
-    "prio1": ["-DDM16_ALT_PRIO=1"], "prio2": ["-DDM16_ALT_PRIO=2"], "prio4": ["-DDM16_ALT_PRIO=4"], "prio12": ["-DDM16_ALT_PRIO=12"],
-    "prio2trace": ["-DDM16_ALT_PRIO=2", "-DDM_TRACE"],
     "trace": ["-DDM_TRACE"],                                   # f16x3 kernel: per-wave timeline of one stage
     "w4": ["-DDM16_WAVES=4", "-DDM16_MT=2"],                   # f16x3 kernel: 4 waves x 2 M-tiles (one wave per SIMD)
     "w4timing": ["-DDM16_WAVES=4", "-DDM16_MT=2", "-DDM_TIMING"],

@@ -12,6 +12,7 @@ for scale in (1.0, 4.0):
     x = synth.synthetic_windows(3000, seed=5)
     x[:50, :, 6] = 3000.0
     ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
+    m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F32)
     p32, c32 = m.predict_windows(x)
     m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3)
     p16, c16 = m.predict_windows(x)

@@ -96,6 +96,7 @@ def extras(m, _lib, model, precision, x_dev0, x_host0, prob_dev, cls_dev, reps=4
     """Untimed-for-`value` side measurements on rank 0 at N = 1: the other MFMA mode on the same batch (kernel
     time from HIP events) and the PCIe-inclusive rate when the boundary is handed pageable host buffers."""
     out = {}
+    m.set_option(_lib.DM_OPT_ASYNC, 0)
     other = "f32" if precision == "f16x3" else "f16x3"
     m.set_precision(other)
     m.predict_windows(x_dev0, prob=prob_dev, cls=cls_dev)
@@ -180,6 +181,9 @@ def main():
     cls_dev = model.DeviceArray((BATCH,), np.uint8, device)
     flag_dev = [model.DeviceArray.from_host(f, device) for f in flag_dev]
     summ = summary.PositionSummary(CONTIG_LEN, device=device)
+    # one in-order device queue: classify -> accumulate -> classify ...; the host only waits at the end of the timed region
+    m.set_option(_lib.DM_OPT_ASYNC, 1)
+    summ.follow(m)
 
     def step(i):
         b = i % n_batches

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libdeepmod_hip.so")
 
 DM_OPT_PROFILE = 1
 DM_OPT_PRECISION = 2
+DM_OPT_ASYNC = 3
 DM_PREC_F32 = 0
 DM_PREC_F16X3 = 1
 (DM_MAP_STATUS, DM_MAP_N_ROWS, DM_MAP_LEFTCLIP, DM_MAP_RIGHTCLIP, DM_MAP_EV_LO, DM_MAP_EV_HI, DM_MAP_FIRST_MATCH_POS,
@@ -51,6 +52,7 @@ SIGNATURES = [
     ("dm_summary_reduce_rccl", _c.c_int, [_vp, _vp, _c.c_int, _c.c_int]),
     ("dm_summary_fetch", _c.c_int, [_vp, _vp, _vp, _vp]),
     ("dm_summary_device_ptr", _vp, [_vp]),
+    ("dm_summary_follow", _c.c_int, [_vp, _vp]),
     ("dm_cluster_create", _vp, [_c.c_int, _vp, _c.c_size_t]),
     ("dm_cluster_destroy", None, [_vp]),
     ("dm_cluster_predict", _c.c_int, [_vp, _vp, _i64, _vp]),

@@ -296,6 +296,7 @@ struct dm_model {
     int64_t stage_rows = 0;  // capacity of d_x in floats
     // profiling
     bool profile = false;
+    bool async = false;                   // DM_OPT_ASYNC: device-resident calls return after enqueue
     int precision = DM_PREC_F16X3;        // default: fastest mode that meets the 1e-4 probability tolerance
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -312,6 +313,7 @@ struct dm_summary {
     unsigned char* d_flags = nullptr;
     int64_t stage_cap = 0;
     hipStream_t stream = nullptr;
+    dm_model* follow = nullptr;   // dm_summary_follow: enqueue on this model's stream (in-order with its launches)
 };
 
 namespace {
@@ -436,7 +438,7 @@ int predict_common(dm_model* m, const float* x, long long xstride, int64_t x_flo
     if (xdev && pdev && cdev) {
         int rc = launch_bilstm(m, x, xstride, n, prob, cls);
         if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (!m->async) HIP_TRY(hipStreamSynchronize(m->stream));
         return DM_OK;
     }
     // host buffers: stage through device memory in batches
@@ -611,6 +613,9 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
         case DM_OPT_PROFILE:
             m->profile = value != 0;
             return DM_OK;
+        case DM_OPT_ASYNC:
+            m->async = value != 0;
+            return DM_OK;
         case DM_OPT_PRECISION:
             if (value != DM_PREC_F32 && value != DM_PREC_F16X3) return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
             m->precision = int(value);
@@ -745,7 +750,8 @@ void dm_summary_destroy(dm_summary* s) {
 
 int64_t dm_summary_length(const dm_summary* s) { return s ? s->length : 0; }
 
-static int summary_add_impl(dm_summary* s, const int64_t* pos, const uint8_t* flags, const uint8_t* cls, int64_t n) {
+static int summary_add_impl(dm_summary* s, const int64_t* pos, const uint8_t* flags, const uint8_t* cls, int64_t n,
+                            bool* deferred = nullptr) {
     if (!s) return fail(DM_EINVAL, "null summary");
     if (n < 0) return fail(DM_EINVAL, "negative count");
     if (n == 0) return DM_OK;
@@ -781,7 +787,15 @@ static int summary_add_impl(dm_summary* s, const int64_t* pos, const uint8_t* fl
     }
     const int threads = 256;
     const int blocks = int(std::min<int64_t>((n + threads - 1) / threads, 2048));
-    hipLaunchKernelGGL(summary_add_kernel, dim3(blocks), dim3(threads), 0, s->stream, s->d_counts,
+    hipStream_t st = s->stream;
+    if (s->follow) {
+        if (pd && fd && cd) {
+            st = s->follow->stream;                                 // device-resident inputs: one in-order queue with the classifier
+            if (deferred && s->follow->async) *deferred = true;     // out-of-range check waits for dm_summary_sync / fetch
+        }
+        else HIP_TRY(hipStreamSynchronize(s->follow->stream));      // staged inputs travel on the summary's own stream
+    }
+    hipLaunchKernelGGL(summary_add_kernel, dim3(blocks), dim3(threads), 0, st, s->d_counts,
                        s->d_counts + s->length, s->d_counts + 2 * s->length, (long long)s->length, dpos, dfl, dcl,
                        (long long)n, s->d_oob);
     HIP_TRY(hipGetLastError());
@@ -790,6 +804,7 @@ static int summary_add_impl(dm_summary* s, const int64_t* pos, const uint8_t* fl
 
 static int summary_check_oob(dm_summary* s) {
     int oob = 0;
+    if (s->follow) HIP_TRY(hipStreamSynchronize(s->follow->stream));
     HIP_TRY(hipMemcpyAsync(&oob, s->d_oob, sizeof(int), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (oob) {
@@ -800,16 +815,18 @@ static int summary_check_oob(dm_summary* s) {
 }
 
 int dm_summary_add(dm_summary* s, const int64_t* pos, const uint8_t* flags, int64_t n) {
-    int rc = summary_add_impl(s, pos, flags, nullptr, n);
-    if (rc || n <= 0) return rc;
+    bool deferred = false;
+    int rc = summary_add_impl(s, pos, flags, nullptr, n, &deferred);
+    if (rc || n <= 0 || deferred) return rc;
     return summary_check_oob(s);  // synchronous on return (the caller may reuse its buffers)
 }
 
 int dm_summary_add_classified(dm_summary* s, const int64_t* pos, const uint8_t* flags, const uint8_t* cls,
                               int64_t n) {
     if (n > 0 && !cls) return fail(DM_EINVAL, "null cls");
-    int rc = summary_add_impl(s, pos, flags, cls, n);
-    if (rc || n <= 0) return rc;
+    bool deferred = false;
+    int rc = summary_add_impl(s, pos, flags, cls, n, &deferred);
+    if (rc || n <= 0 || deferred) return rc;
     return summary_check_oob(s);
 }
 
@@ -832,6 +849,15 @@ int dm_summary_fetch(dm_summary* s, int32_t* touch, int32_t* cov, int32_t* mod) 
 }
 
 void* dm_summary_device_ptr(dm_summary* s) { return s ? s->d_counts : nullptr; }
+
+int dm_summary_follow(dm_summary* s, dm_model* m) {
+    if (!s) return fail(DM_EINVAL, "null summary");
+    if (m && m->device != s->device) return fail(DM_EINVAL, "summary (device %d) cannot follow a model on device %d", s->device, m->device);
+    if (s->follow) HIP_TRY(hipStreamSynchronize(s->follow->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->follow = m;
+    return DM_OK;
+}
 
 // ------------------------------------------------------------------------------- cluster ----
 struct dm_cluster {
@@ -968,6 +994,7 @@ int dm_summary_reduce_rccl(dm_summary* s, const void* unique_id128, int rank, in
     void* comm = nullptr;
     int e = g_rccl.init(&comm, nranks, id, rank);
     if (e) return fail(DM_ERCCL, "ncclCommInitRank: %s", g_rccl.errstr ? g_rccl.errstr(e) : "error");
+    if (s->follow) (void)hipStreamSynchronize(s->follow->stream);   // adds queued on the classifier's stream
     // one in-place sum over touch|cov|mod (int32 = ncclInt32 (2), ncclSum (0)); integer sum is order independent
     e = g_rccl.allreduce(s->d_counts, s->d_counts, size_t(3) * s->length, 2, 0, comm, s->stream);
     hipError_t he = hipStreamSynchronize(s->stream);

@@ -41,6 +41,11 @@ class PositionSummary:
         except Exception:
             pass
 
+    def follow(self, model=None):
+        """Enqueue device-resident adds on `model`'s stream (in order with its launches); None detaches."""
+        _lib.check(self._lib.dm_summary_follow(self._h, model._h if model is not None else None))
+        self._followed = model          # keep the model alive as long as the summary follows it
+
     def add(self, pos, flags, n: Optional[int] = None):
         if not isinstance(pos, DeviceArray):
             pos = np.ascontiguousarray(pos, dtype=np.int64)

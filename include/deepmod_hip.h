@@ -53,6 +53,8 @@ extern "C" {
 /* dm_model_set_option keys */
 #define DM_OPT_PROFILE 1   /* 1: bracket every kernel launch with HIP events on the model's stream */
 #define DM_OPT_PRECISION 2 /* DM_PREC_*; default DM_PREC_F16X3 */
+#define DM_OPT_ASYNC 3     /* 1: dm_predict_* with device-resident buffers return after enqueue on the model's stream;
+                              wait with dm_model_sync.  Default 0: every call is synchronous on return. */
 #define DM_PREC_F32 0      /* fp32 MFMA (v_mfma_f32_16x16x4_f32): fp32 products, the TF graph's own arithmetic */
 #define DM_PREC_F16X3 1    /* split-f16 MFMA: every fp32 operand = hi + lo f16, 3 products per fp32 product, fp32
                               accumulation; max |dp| vs the oracle 1e-6 .. 2e-6 (tolerance of the path: 1e-4), 2.5x faster */
@@ -135,6 +137,11 @@ int dm_summary_reduce_rccl(dm_summary* s, const void* unique_id128, int rank, in
 int dm_summary_fetch(dm_summary* s, int32_t* touch, int32_t* cov, int32_t* mod);
 /* raw device pointers (3 * length int32: touch | cov | mod) for callers that run their own collective */
 void* dm_summary_device_ptr(dm_summary* s);
+/* Enqueue this summary's device-resident adds on model m's stream, i.e. in order with its classifier launches (with
+ * DM_OPT_ASYNC the host then never waits between classify and accumulate, and the out-of-range check of those adds is
+ * reported by the next dm_summary_sync / dm_summary_fetch instead); m = NULL detaches.  Detach or destroy the summary
+ * before destroying the model. */
+int dm_summary_follow(dm_summary* s, dm_model* m);
 
 /* ------------------------------------------------------------- CpG cluster second stage -- */
 /*

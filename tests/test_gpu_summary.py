@@ -86,3 +86,46 @@ def test_bed_bytes_from_gpu_counts(gpu_device):
     bed = summary.bed_lines("chrS", "+", "C", t, c, m)
     assert bed == (b"chrS 7 8 C 3 + 7 8 0,0,0 3 33 1 \n"
                    b"chrS 9 10 C 0 + 9 10 0,0,0 0 0 0 \n")
+
+
+def test_async_classify_accumulate_queue_equals_synchronous_calls(gpu_device):
+    """DM_OPT_ASYNC + dm_summary_follow: classify -> accumulate -> classify ... on one in-order stream without host
+    waits gives the same counters as the synchronous calls; a deferred out-of-range error surfaces at sync."""
+    from deepmod_amd import _lib, model, summary, synth
+    w = synth.synthetic_weights(26, 4.0)
+    n, length = 20000, 50000
+    rng = np.random.default_rng(3)
+    xs = [synth.synthetic_windows(n, seed=50 + i) for i in range(3)]
+    poss = [rng.integers(0, length, n).astype(np.int64) for _ in range(3)]
+    flags = [(rng.integers(0, 4, n)).astype(np.uint8) for _ in range(3)]
+
+    def run(async_mode):
+        m = model.BiLSTMModel(w, 0)
+        s = summary.PositionSummary(length, 0)
+        dx = [model.DeviceArray.from_host(x, 0) for x in xs]
+        dp = [model.DeviceArray.from_host(p, 0) for p in poss]
+        df = [model.DeviceArray.from_host(f, 0) for f in flags]
+        dc = model.DeviceArray((n,), np.uint8, 0)
+        if async_mode:
+            m.set_option(_lib.DM_OPT_ASYNC, 1)
+            s.follow(m)
+        for i in range(3):
+            m.predict_windows(dx[i], cls=dc, want_prob=False)
+            s.add_classified(dp[i], df[i], dc, n)
+        m.sync()
+        out = s.fetch()
+        if async_mode:      # an out-of-range position is reported at the next sync, not at the add
+            bad = model.DeviceArray.from_host(np.array([length + 5], np.int64), 0)
+            one = model.DeviceArray.from_host(np.array([3], np.uint8), 0)
+            s.add_classified(bad, one, one, 1)
+            with pytest.raises(_lib.DeepModHipError):
+                s.sync()
+            s.follow(None)
+        s.close()
+        m.close()
+        return out
+
+    a, b = run(False), run(True)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    assert int(a[1].sum()) > 0

@@ -16,6 +16,7 @@ VARIANTS = {
     "nodma": ["-DDM_ABL_NODMA"],
     "noldsb": ["-DDM16_ABL_NOLDSB"], "nodma16": ["-DDM16_ABL_NODMA"], "noldsb_nodma": ["-DDM16_ABL_NOLDSB", "-DDM16_ABL_NODMA"],
     "nsplit": ["-DDM16_NSPLIT"], "nsplit_timing": ["-DDM16_NSPLIT", "-DDM_TIMING"], "nsplit_trace": ["-DDM16_NSPLIT", "-DDM_TRACE"],
+    "piece2": ["-DDM16_PIECE_EVERY=2"], "piece3": ["-DDM16_PIECE_EVERY=3"],
     "trace": ["-DDM_TRACE"],                                   # f16x3 kernel: per-wave timeline of one stage
     "w4": ["-DDM16_WAVES=4", "-DDM16_MT=2"],                   # f16x3 kernel: 4 waves x 2 M-tiles (one wave per SIMD)
     "w4timing": ["-DDM16_WAVES=4", "-DDM16_MT=2", "-DDM_TIMING"],

@@ -21,6 +21,12 @@
 #include "lstm_f16.hip.inc"
 #endif
 
+#ifdef DM_TRACE2
+#define DM16_TRACE2_LDS 2048
+#else
+#define DM16_TRACE2_LDS 0
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -352,7 +358,7 @@ int ensure_f16(dm_model* m) {
     HIP_TRY(hipMalloc(&m->d_wout, 400 * sizeof(float)));
     HIP_TRY(hipMemcpy(m->d_wout, wout, 400 * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16::bilstm_f16x3_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16::LDS_BYTES)));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16::LDS_BYTES) + DM16_TRACE2_LDS));
     return DM_OK;
 }
 
@@ -396,7 +402,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         p.ntiles = int((n + TILE_M - 1) / TILE_M);
         p.dbg = m->d_dbg;
         const int grid = std::min(p.ntiles, m->grid_cap);
-        hipLaunchKernelGGL(bilstm_f16x3_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
+        hipLaunchKernelGGL(bilstm_f16x3_kernel, dim3(grid), dim3(THREADS), LDS_BYTES + DM16_TRACE2_LDS, m->stream, p);
     } else {
         using namespace lstm32;
         Params p;
@@ -524,7 +530,7 @@ int model_init(dm_model* m, const float* weights) {
     const size_t scratch_bytes = size_t(m->grid_cap) * std::max(SCRATCH_FLOATS_PER_WG * sizeof(float), lstm16::SCRATCH_BYTES_PER_WG);
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
     HIP_TRY(hipMemset(m->d_scratch, 0, scratch_bytes));
-#if defined(DM_TIMING) || defined(DM_TRACE)
+#if defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2)
     HIP_TRY(hipMalloc(&m->d_dbg, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(m->d_dbg, 0, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long)));
 #endif

@@ -16,6 +16,11 @@ VARIANTS = {
     "nodma": ["-DDM_ABL_NODMA"],
     "noldsb": ["-DDM16_ABL_NOLDSB"], "nodma16": ["-DDM16_ABL_NODMA"], "noldsb_nodma": ["-DDM16_ABL_NOLDSB", "-DDM16_ABL_NODMA"],
     "nsplit": ["-DDM16_NSPLIT"], "nsplit_timing": ["-DDM16_NSPLIT", "-DDM_TIMING"], "nsplit_trace": ["-DDM16_NSPLIT", "-DDM_TRACE"],
+    "bdepth1": ["-DDM16_BDEPTH=1"], "bdepth3": ["-DDM16_BDEPTH=3"], "bdepth4": ["-DDM16_BDEPTH=4"],
+    "tiles3": ["-DDM_TRACE2=3"], "tiles0": ["-DDM_TRACE2=0"], "tiles6": ["-DDM_TRACE2=6"],
+    "nobar16": ["-DDM16_ABL_NOBAR"], "nobar_nodma16": ["-DDM16_ABL_NOBAR", "-DDM16_ABL_NODMA"], "skeleton16": ["-DDM16_ABL_NOBAR", "-DDM16_ABL_NODMA", "-DDM16_ABL_NOLDSB"],
+    "noldsb_nz": ["-DDM16_ABL_NOLDSB", "-DDM16_ABL_NOLDSB_NONZERO"],
+    "defer": ["-DDM16_DEFER"], "defer_trace": ["-DDM16_DEFER", "-DDM_TRACE"],
     "piece2": ["-DDM16_PIECE_EVERY=2"], "piece3": ["-DDM16_PIECE_EVERY=3"],
     "trace": ["-DDM_TRACE"],                                   # f16x3 kernel: per-wave timeline of one stage
     "w4": ["-DDM16_WAVES=4", "-DDM16_MT=2"],                   # f16x3 kernel: 4 waves x 2 M-tiles (one wave per SIMD)
@@ -68,6 +73,20 @@ def run(names, n=65536, reps=6):
         res[name] = ms / launches
         print("%-14s %.3f ms/launch  %.3g windows/s  %.1f%% of fp32 MFMA peak" %
               (name, res[name], n / res[name] * 1e3, n * 8.924e6 / (res[name] * 1e-3) / 157.3e12 * 100), flush=True)
+        if name.startswith("tiles"):
+            import ctypes
+            lib = _lib.load()
+            lib.dm_debug_timing.restype = ctypes.c_longlong
+            lib.dm_debug_timing.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong]
+            cnt = lib.dm_debug_timing(m._h, None, 0)
+            buf = np.zeros(cnt, np.uint64)
+            lib.dm_debug_timing(m._h, buf.ctypes.data, cnt)
+            t = buf[:256].reshape(8, 32).astype(np.int64)[:, :27]
+            t0 = t[:, 0].min()
+            print("   per-tile start times of one MFMA block (cycles after the first wave entered it); last two rows: block end, barrier exit")
+            print("   %-8s" % "tile" + "".join("  wave%d" % w for w in range(8)))
+            for i in range(27):
+                print("   %-8s" % (i if i < 25 else ("end", "barrier")[i - 25]) + "".join("%7d" % (t[w, i] - t0) for w in range(8)))
         if "trace" in name:
             import ctypes
             lib = _lib.load()

@@ -77,6 +77,17 @@ def load_feature_container(path: str) -> List[Dict]:
     return reads
 
 
+def savez_fast(path: str, arrays: Dict) -> None:
+    """np.savez_compressed with deflate level 1: the reference gzip-compresses its per-read tables too (myDetect.py:752),
+    but zlib's default level made the store 60 % of a worker's host time; level 1 is ~4x faster for +15 % bytes.
+    np.load reads the result like any .npz."""
+    import zipfile
+    with zipfile.ZipFile(path, 'w', zipfile.ZIP_DEFLATED, compresslevel=1) as zf:
+        for name, arr in arrays.items():
+            with zf.open(name + '.npy', 'w', force_zip64=True) as fh:
+                np.lib.format.write_array(fh, np.asanyarray(arr), allow_pickle=False)
+
+
 class PredWriter:
     """Collects the per-read prediction tables of one worker batch (file name and index-line fields
     follow myDetect.py:716-718)."""
@@ -122,8 +133,7 @@ class PredWriter:
             return
         self.arrays['attrs'] = np.array(json.dumps(self.attrs))
         os.makedirs(os.path.dirname(self.path), exist_ok=True)
-        with open(self.path, 'wb') as fh:
-            np.savez_compressed(fh, **self.arrays)
+        savez_fast(self.path, self.arrays)
 
 
 _cache = {'path': None, 'z': None, 'attrs': None}

@@ -47,7 +47,7 @@ def build(names):
 PREC = int(os.environ.get('DM_ABL_PREC', '0'))
 
 
-def run(names, n=65536, reps=6):
+def run(names, n=65536, reps=int(os.environ.get('DM_ABL_REPS', '6'))):
     sys.path.insert(0, ROOT)
     import numpy as np
     from deepmod_amd import _lib, model, synth

@@ -32,7 +32,8 @@ PRECISIONS = {
     "f16x3": {"peak": 2500.0, "kernel": "lstm16::bilstm_f16x3_kernel", "dtype": "f16x3",
               "label": "split-f16 MFMA (hi+lo f16 operands, 3 products per fp32 product, fp32 accumulate)",
               "peak_note": "v_mfma_f32_16x16x32_f16 dense 16-bit peak 2.5 PF; the split issues 3 products x 576/507 K padding = "
-                           "3.41 matrix FLOP per algorithmic FLOP, so frac <= 0.293 by construction",
+                           "3.41 matrix FLOP per algorithmic FLOP, so frac <= 0.293 by construction; a pure MFMA loop on "
+                           "non-zero data sustains 2.0-2.1 PF on this part (2.03 GHz, profiles/r01/ubench_mfma_zero.txt)",
               "issued_per_algorithmic": 3.0 * 576.0 / 507.0},
     "f32": {"peak": 157.3, "kernel": "lstm32::bilstm_f32_kernel", "dtype": "f32", "label": "fp32 MFMA",
             "peak_note": "v_mfma_f32_16x16x4_f32 dense fp32, 157.3 TF"},

@@ -67,6 +67,9 @@ inline int gate_col(int t, int c) {
     if (t < 24) return (t & 3) * 100 + 16 * (t >> 2) + c;
     return (c >> 2) * 100 + 96 + (c & 3);
 }
+// exponent scale folded into kernel and bias columns (both kernels): the cell update takes 2^x of the accumulators as
+// they are - i, f, o columns x -log2(e) (sigmoid = 1 / (1 + 2^a)), j column x 2 log2(e) (tanh = (2^a - 1) / (2^a + 1))
+inline float gate_scale(int gc) { return (gc >= 100 && gc < 200) ? 2.8853900817779268f : -1.4426950408889634f; }
 
 struct Packed {
     std::vector<float> w, b, h;
@@ -101,7 +104,7 @@ Packed pack_weights(const float* flat) {
                         krow = kin + 4 * (ks - ksin) + sub;
                     }
                     for (int t = 0; t < NT; ++t) {
-                        const float v = krow < 0 ? 0.0f : kern[size_t(krow) * 400 + gate_col(t, c)];
+                        const float v = krow < 0 ? 0.0f : kern[size_t(krow) * 400 + gate_col(t, c)] * gate_scale(gate_col(t, c));
                         if (t < 24) dst[((t >> 2) * 64 + lane) * 4 + (t & 3)] = v;   // [tile quad][lane][4]
                         else dst[6 * 256 + lane] = v;                                // tile 24: [lane]
                     }
@@ -111,7 +114,7 @@ Packed pack_weights(const float* flat) {
             for (int t = 0; t < NT; ++t)
                 for (int c = 0; c < 16; ++c) {
                     const int gc = gate_col(t, c);
-                    bd[t * 16 + c] = bias[gc] + ((gc >= 200 && gc < 300) ? 1.0f : 0.0f);  // forget_bias=1.0
+                    bd[t * 16 + c] = (bias[gc] + ((gc >= 200 && gc < 300) ? 1.0f : 0.0f)) * gate_scale(gc);  // forget_bias=1.0
                 }
             ks_base += ksin + 25;
         }
@@ -166,8 +169,7 @@ Packed16 pack_weights_f16(const float* flat) {
                             const int gc = gate_col(t, lane & 15);
                             float v = krow < 0 ? 0.0f : kern[size_t(krow) * 400 + gc];
                             if (k == own_k0 + HID) v = bias[gc] + ((gc >= 200 && gc < 300) ? 1.0f : 0.0f);   // bias row (+ forget_bias)
-                            // exponent scales folded into the GEMM (lstm16::lstm_cells): i, f, o -> -log2(e), j -> 2 log2(e)
-                            v *= (gc >= 100 && gc < 200) ? 2.8853900817779268f : -1.4426950408889634f;
+                            v *= gate_scale(gc);
                             const _Float16 hi = (_Float16)v;
                             const _Float16 lo = (_Float16)(v - (float)hi);
                             dst[((size_t(t) * 2 + 0) * 64 + lane) * 8 + j] = hi;

@@ -232,3 +232,38 @@ def test_map_read_matches_oracle_on_random_records(hip_lib):
             assert (mp['ev_lo'], mp['ev_hi']) == (o['ev_lo'], o['ev_hi']), (it, cigar)
         assert (mp['first_match_pos'], mp['last_match_pos']) == (o['first_match_pos'], o['last_match_pos'])
     assert n_ok > 400
+
+
+def test_region_and_contig_filters(golden, hip_lib):
+    """--region / --ConUnk semantics of handle_record (myDetect.py:501-511, :544-553)."""
+    f5data, f5align = _inputs(golden)
+    base = {'ConUnk': True, 'outLevel': 3, 'fnum': 7, 'windowsize': 21, 'wrkBase': '/wrk', 'outFolder': '/tmp/', 'FileID': 'mod'}
+
+    def names(mo):
+        sp_options = defaultdict()
+        sp_options.update({'Mod': [], 'Error': defaultdict(list)})
+        sp_param = defaultdict()
+        sp_param.update({'f5data': f5data, 'ref_info': {'chrS': golden['genome'], 'chrU_random': golden['genome']}, 'f5status': '', 'line': ''})
+        return sorted(rd['readk'] for rd in readmap.map_records(dict(base, **mo), sp_options, sp_param, f5align, f5data))
+
+    everything = names({'region': [[None, None, None]]})
+    assert 'unknown_contig' in everything                                   # ConUnk=True keeps names with '_'
+    assert 'unknown_contig' not in names({'region': [[None, None, None]], 'ConUnk': False})
+    assert names({'region': [['chrX', None, None]]}) == []                  # other chromosome
+    only = names({'region': [['chrS', 1900, 2700]]})                        # pos > 1900 and pos + len(events) < 2700
+    assert only == ['hard_clips']
+    assert set(names({'region': [['chrS', None, 1500]]})) <= {'plain_fwd', 'plain_rev', 'cpg_swap_fwd', 'cpg_swap_rev'}
+
+
+def test_raw_batch_without_alignment_goes_to_error_channel(tmp_path, hip_lib, monkeypatch):
+    """No aligner on PATH and no side-car SAM -> every read of the batch is reported under the reference's key."""
+    from deepmod_amd import synth_reads
+    files, fasta = synth_reads.write_synthetic_raw_run(str(tmp_path / 'raw'), n_reads=3, reads_per_file=3, genome_len=5000, seed=2,
+                                                       chrom='chrS', min_len=200, max_len=300)
+    os.remove(files[0][:-len(rawreads.RAW_SUFFIX)] + '.sam')
+    f5data = {'r%d' % i: ('ACGT', None, None, files[0], (0, 0)) for i in range(3)}
+    monkeypatch.setattr(rawreads, 'get_Event_Signals', lambda mo, so, fl: f5data)
+    sp_options = defaultdict()
+    sp_options.update({'Mod': [], 'Error': defaultdict(list), 'ctfolder': str(tmp_path), 'batchid': 0})
+    detect.mDetect1_raw({'alignStr': 'no-such-aligner', 'Ref': fasta}, sp_options, None, files)
+    assert sp_options['Error'] == {'Cannot running aligment': [files[0]] * 3}

@@ -57,7 +57,7 @@ extern "C" {
                               wait with dm_model_sync.  Default 0: every call is synchronous on return. */
 #define DM_PREC_F32 0      /* fp32 MFMA (v_mfma_f32_16x16x4_f32): fp32 products, the TF graph's own arithmetic */
 #define DM_PREC_F16X3 1    /* split-f16 MFMA: every fp32 operand = hi + lo f16, 3 products per fp32 product, fp32
-                              accumulation; max |dp| vs the oracle 1e-6 .. 2e-6 (tolerance of the path: 1e-4), 2.5x faster */
+                              accumulation; max |dp| vs the oracle 1e-6 .. 2e-6 (tolerance of the path: 1e-4), ~3x faster */
 
 typedef struct dm_model dm_model;
 typedef struct dm_summary dm_summary;

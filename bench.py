@@ -39,6 +39,7 @@ PRECISIONS = {
             "peak_note": "v_mfma_f32_16x16x4_f32 dense fp32, 157.3 TF"},
 }
 CONTIG_LEN = 4_641_652        # E. coli K-12 sized contig for the synthetic summary
+SETUP_LAUNCHES = 32           # untimed classifier launches during setup (GPU power-state warm-up), reported in the JSON
 
 
 def usable_cores():
@@ -206,6 +207,12 @@ def main():
         except Exception:
             torch = None
 
+    # setup, untimed like the data upload above: bring the GPU out of its idle power state (the first ~10 launches of a
+    # process run ~15 % slower than the steady state, profiles/r01/README.md) so that a short --steps run measures the
+    # same clocks as a long one; then the W warmup steps the caller asked for
+    for i in range(SETUP_LAUNCHES):
+        m.predict_windows(x_dev[i % n_batches], prob=prob_dev, cls=cls_dev)
+    sync_all()
     for i in range(args.warmup):
         step(i)
     sync_all()
@@ -244,7 +251,7 @@ def main():
             "config": {"workload": "configs[1]: rnn_conmodC_P100wd21_f7ne1u0_4 geometry (3x100 BiLSTM, wd21, f7), "
                                    "synthetic weights (real .data shards absent), %d windows/step resident in HBM, "
                                    "%d distinct batches (1,048,576 windows)" % (BATCH, n_batches),
-                       "batch": BATCH, "windows_total": total_windows, "parallelism": "window-sharded x%d" % world, "forced_dist_dry_run": bool(dist_mode and world == 1),
+                       "batch": BATCH, "windows_total": total_windows, "parallelism": "window-sharded x%d" % world, "forced_dist_dry_run": bool(dist_mode and world == 1), "setup_launches": SETUP_LAUNCHES,
                        "precision": P["label"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": P["peak"], "unit": "TFLOP/s",
                          "frac": achieved / P["peak"], "traffic": (traffic or {}).get("bytes"),

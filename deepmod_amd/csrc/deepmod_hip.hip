@@ -291,7 +291,7 @@ struct dm_model {
     float* d_wout = nullptr;              // head W[200][2] fp32 (DM_PREC_F16X3)
     float* d_scratch = nullptr;
     unsigned long long* d_dbg = nullptr;  // DM_TIMING builds only
-    float* d_plogit = nullptr;            // f16x3 dir_split launches: [2][grid_cap / 2 * 128][2] partial logits
+    float* d_plogit = nullptr;            // dir_split launches: [2][(grid_cap / 2 + 1) * 128][2] partial logits
     float bout[2] = {0, 0};
     int grid_cap = 0;
     std::vector<float> host_weights;      // canonical blob, kept for lazy packing of other precisions
@@ -360,7 +360,6 @@ int ensure_f16(dm_model* m) {
     const float* wout = m->host_weights.data() + (DM_WEIGHT_FLOATS - 402);
     HIP_TRY(hipMalloc(&m->d_wout, 400 * sizeof(float)));
     HIP_TRY(hipMemcpy(m->d_wout, wout, 400 * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&m->d_plogit, size_t(2) * (size_t(m->grid_cap) / 2 + 1) * lstm16::TILE_M * 2 * sizeof(float)));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16::bilstm_f16x3_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16::LDS_BYTES) + DM16_TRACE2_LDS));
     return DM_OK;
@@ -434,8 +433,15 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         p.scratch = m->d_scratch;
         p.ntiles = int((n + TILE_M - 1) / TILE_M);
         p.dbg = m->d_dbg;
-        const int grid = std::min(p.ntiles, m->grid_cap);
+        p.dir_split = (2 * p.ntiles <= m->grid_cap) ? 1 : 0;     // small batch: one direction per workgroup
+        p.plogit = m->d_plogit;
+        const int grid = std::min(p.dir_split ? 2 * p.ntiles : p.ntiles, m->grid_cap);
         hipLaunchKernelGGL(bilstm_f32_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
+        if (p.dir_split) {
+            const long long npad = (long long)p.ntiles * TILE_M;
+            hipLaunchKernelGGL(lstm16::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit,
+                               (long long)n, npad, m->bout[0], m->bout[1], d_prob, d_cls);
+        }
     }
     HIP_TRY(hipGetLastError());
     if (m->profile) {
@@ -542,6 +548,8 @@ int model_init(dm_model* m, const float* weights) {
     HIP_TRY(hipMemcpy(m->d_wpack, P.w.data(), P.w.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_bpack, P.b.data(), P.b.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_hpack, P.h.data(), P.h.size() * sizeof(float), hipMemcpyHostToDevice));
+    // partial logits of direction-split launches (small batches, both kernels): [2][grid_cap / 2 + 1 tiles][128][2]
+    HIP_TRY(hipMalloc(&m->d_plogit, size_t(2) * (size_t(m->grid_cap) / 2 + 1) * lstm16::TILE_M * 2 * sizeof(float)));
     const size_t scratch_bytes = size_t(m->grid_cap) * std::max(SCRATCH_FLOATS_PER_WG * sizeof(float), lstm16::SCRATCH_BYTES_PER_WG);
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
     HIP_TRY(hipMemset(m->d_scratch, 0, scratch_bytes));

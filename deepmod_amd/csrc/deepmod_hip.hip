@@ -291,7 +291,8 @@ struct dm_model {
     float* d_wout = nullptr;              // head W[200][2] fp32 (DM_PREC_F16X3)
     float* d_scratch = nullptr;
     unsigned long long* d_dbg = nullptr;  // DM_TIMING builds only
-    float* d_plogit = nullptr;            // dir_split launches: [2][(grid_cap / 2 + 1) * 128][2] partial logits
+    float* d_plogit = nullptr;            // partial logits [2 directions][plogit_tiles * 128][2], grown on demand
+    int64_t plogit_tiles = 0;
     float bout[2] = {0, 0};
     int grid_cap = 0;
     std::vector<float> host_weights;      // canonical blob, kept for lazy packing of other precisions
@@ -352,6 +353,20 @@ int flush_profile(dm_model* m) {
     return DM_OK;
 }
 
+// partial-logit buffer of direction-split launches: 16 B per window, grown on demand (a running launch may still use the
+// old buffer: wait for the stream before freeing it)
+int ensure_plogit(dm_model* m, int64_t ntiles) {
+    if (ntiles <= m->plogit_tiles) return DM_OK;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    (void)hipFree(m->d_plogit);
+    m->d_plogit = nullptr;
+    m->plogit_tiles = 0;
+    const int64_t cap = std::max<int64_t>(ntiles + ntiles / 4, 1024);
+    HIP_TRY(hipMalloc(&m->d_plogit, size_t(2) * size_t(cap) * lstm16::TILE_M * 2 * sizeof(float)));
+    m->plogit_tiles = cap;
+    return DM_OK;
+}
+
 int ensure_f16(dm_model* m) {
     if (m->d_wpack16) return DM_OK;
     Packed16 P = pack_weights_f16(m->host_weights.data());
@@ -407,8 +422,12 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
 #ifdef DM16_NSPLIT
         p.dir_split = 0;
 #else
-        p.dir_split = (2 * p.ntiles <= m->grid_cap) ? 1 : 0;     // small batch: one direction per workgroup
+        p.dir_split = 1;      // work item = (tile, direction): half the latency of small batches, finer tail on large ones
 #endif
+        if (p.dir_split) {
+            int rcp = ensure_plogit(m, p.ntiles);
+            if (rcp) return rcp;
+        }
         p.plogit = m->d_plogit;
         const int grid = std::min(p.dir_split ? 2 * p.ntiles : p.ntiles, m->grid_cap);
         hipLaunchKernelGGL(bilstm_f16x3_kernel, dim3(grid), dim3(THREADS), LDS_BYTES + DM16_TRACE2_LDS, m->stream, p);
@@ -433,7 +452,11 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         p.scratch = m->d_scratch;
         p.ntiles = int((n + TILE_M - 1) / TILE_M);
         p.dbg = m->d_dbg;
-        p.dir_split = (2 * p.ntiles <= m->grid_cap) ? 1 : 0;     // small batch: one direction per workgroup
+        p.dir_split = 1;      // work item = (tile, direction), see above
+        {
+            int rcp = ensure_plogit(m, p.ntiles);
+            if (rcp) return rcp;
+        }
         p.plogit = m->d_plogit;
         const int grid = std::min(p.dir_split ? 2 * p.ntiles : p.ntiles, m->grid_cap);
         hipLaunchKernelGGL(bilstm_f32_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
@@ -548,8 +571,6 @@ int model_init(dm_model* m, const float* weights) {
     HIP_TRY(hipMemcpy(m->d_wpack, P.w.data(), P.w.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_bpack, P.b.data(), P.b.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_hpack, P.h.data(), P.h.size() * sizeof(float), hipMemcpyHostToDevice));
-    // partial logits of direction-split launches (small batches, both kernels): [2][grid_cap / 2 + 1 tiles][128][2]
-    HIP_TRY(hipMalloc(&m->d_plogit, size_t(2) * (size_t(m->grid_cap) / 2 + 1) * lstm16::TILE_M * 2 * sizeof(float)));
     const size_t scratch_bytes = size_t(m->grid_cap) * std::max(SCRATCH_FLOATS_PER_WG * sizeof(float), lstm16::SCRATCH_BYTES_PER_WG);
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
     HIP_TRY(hipMemset(m->d_scratch, 0, scratch_bytes));

@@ -50,6 +50,10 @@ def build_parser():
     det.add_argument('--Base', default='C', choices=['A', 'C', 'G', 'T'], help='base of interest')
     det.add_argument('--mod_cluster', default=0, type=int, choices=[0, 1], help='only 0 is built')
     det.add_argument('--gpus', type=int, default=None, help='GPUs to spread the workers over (default: all visible)')
+    det.add_argument('--storePred', type=int, choices=[0, 1], default=0,
+                     help='0 (default): streaming detect - per-position counters stay on the GPUs, one RCCL reduce per contig x strand, '
+                          'no per-read files; 1: also keep the per-read prediction tables and index files of the reference '
+                          '(needed for a later --predDet 0 run)')
     det.set_defaults(func=mDetect)
     for name in ('train', 'getfeatures'):
         p = sub.add_parser(name, help='not built: training-side, outside the accelerated path')
@@ -61,9 +65,11 @@ def mDetect(args):
     from deepmod_amd import _lib, detect
     mo = {k: getattr(args, k) for k in ('outLevel', 'wrkBase', 'FileID', 'outFolder', 'recursive', 'threads', 'files_per_thread',
                                          'windowsize', 'predDet', 'predpath', 'modfile', 'fnum', 'hidden', 'outputlayer', 'Base',
-                                         'mod_cluster', 'Ref', 'alignStr', 'SignalGroup', 'basecall_1d', 'basecall_2strand')}
+                                         'mod_cluster', 'Ref', 'alignStr', 'SignalGroup', 'basecall_1d', 'basecall_2strand', 'storePred')}
     for k in ('threads', 'files_per_thread', 'windowsize', 'fnum', 'hidden'):
         non_negative(mo[k], k)
+    if mo['threads'] < 1:
+        mo['threads'] = 1                                # bin/DeepMod.py:78: at least one worker
     if mo['files_per_thread'] < 2:
         mo['files_per_thread'] = 2                       # bin/DeepMod.py:75-76
     if mo['windowsize'] % 2 == 0:

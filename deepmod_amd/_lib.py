@@ -14,6 +14,8 @@ DM_OPT_PRECISION = 2
 DM_OPT_ASYNC = 3
 DM_PREC_F32 = 0
 DM_PREC_F16X3 = 1
+DM_INFO_PRECISION, DM_INFO_F16_REPRESENTABLE, DM_INFO_F16_LENGTH_SHIFT, DM_INFO_DEVICE = 1, 2, 3, 4
+DM_OK, DM_EINVAL, DM_EDEVICE, DM_ENOMEM, DM_ESTATE, DM_ERCCL, DM_ERANGE = 0, -1, -2, -3, -4, -5, -6
 (DM_MAP_STATUS, DM_MAP_N_ROWS, DM_MAP_LEFTCLIP, DM_MAP_RIGHTCLIP, DM_MAP_EV_LO, DM_MAP_EV_HI, DM_MAP_FIRST_MATCH_POS,
  DM_MAP_LAST_MATCH_POS, DM_MAP_NUM_INSERT, DM_MAP_NUM_DELETE, DM_MAP_NUM_MISMATCH, DM_MAP_STRAND, DM_MAP_POS_AFTER_CLIP,
  DM_MAP_EVENTS_AFTER_CLIP) = range(14)
@@ -33,6 +35,7 @@ SIGNATURES = [
     ("dm_model_create", _vp, [_c.c_int, _vp, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     ("dm_model_destroy", None, [_vp]),
     ("dm_model_set_option", _c.c_int, [_vp, _c.c_int, _i64]),
+    ("dm_model_get_info", _c.c_int, [_vp, _c.c_int, _c.POINTER(_i64)]),
     ("dm_predict_windows", _c.c_int, [_vp, _vp, _i64, _vp, _vp]),
     ("dm_predict_read", _c.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     ("dm_model_sync", _c.c_int, [_vp]),
@@ -42,14 +45,23 @@ SIGNATURES = [
     ("dm_device_free", _c.c_int, [_c.c_int, _vp]),
     ("dm_memcpy_h2d", _c.c_int, [_c.c_int, _vp, _vp, _c.c_size_t]),
     ("dm_memcpy_d2h", _c.c_int, [_c.c_int, _vp, _vp, _c.c_size_t]),
+    ("dm_model_h2d_async", _c.c_int, [_vp, _vp, _vp, _c.c_size_t]),
     ("dm_summary_create", _vp, [_c.c_int, _i64]),
     ("dm_summary_destroy", None, [_vp]),
     ("dm_summary_length", _i64, [_vp]),
     ("dm_summary_add", _c.c_int, [_vp, _vp, _vp, _i64]),
     ("dm_summary_add_classified", _c.c_int, [_vp, _vp, _vp, _vp, _i64]),
     ("dm_summary_sync", _c.c_int, [_vp]),
+    ("dm_summary_grow", _c.c_int, [_vp, _i64]),
     ("dm_rccl_unique_id", _c.c_int, [_vp]),
-    ("dm_summary_reduce_rccl", _c.c_int, [_vp, _vp, _c.c_int, _c.c_int]),
+    ("dm_comm_create", _vp, [_c.c_int, _vp, _c.c_int, _c.c_int]),
+    ("dm_comm_destroy", None, [_vp]),
+    ("dm_comm_rank", _c.c_int, [_vp]),
+    ("dm_comm_size", _c.c_int, [_vp]),
+    ("dm_comm_barrier", _c.c_int, [_vp]),
+    ("dm_comm_max_f64", _c.c_int, [_vp, _c.POINTER(_c.c_double)]),
+    ("dm_comm_stats", _c.c_int, [_vp, _c.POINTER(_i64), _c.POINTER(_i64)]),
+    ("dm_summary_reduce", _c.c_int, [_vp, _vp, _c.c_int]),
     ("dm_summary_fetch", _c.c_int, [_vp, _vp, _vp, _vp]),
     ("dm_summary_device_ptr", _vp, [_vp]),
     ("dm_summary_follow", _c.c_int, [_vp, _vp]),
@@ -64,7 +76,12 @@ SIGNATURES = [
 
 
 class DeepModHipError(RuntimeError):
-    pass
+    code = None
+
+
+class DeepModRangeError(DeepModHipError):
+    """DM_ERANGE: the split-f16 kernel met an input it cannot represent; repeat the call with precision 'f32'."""
+    code = DM_ERANGE
 
 
 _LIB: Optional[ctypes.CDLL] = None
@@ -89,7 +106,12 @@ def load() -> ctypes.CDLL:
 
 def check(rc: int) -> None:
     if rc != 0:
-        raise DeepModHipError("deepmod_hip error %d: %s" % (rc, load().dm_last_error().decode("utf-8", "replace")))
+        msg = "deepmod_hip error %d: %s" % (rc, load().dm_last_error().decode("utf-8", "replace"))
+        if rc == DM_ERANGE:
+            raise DeepModRangeError(msg)
+        err = DeepModHipError(msg)
+        err.code = rc
+        raise err
 
 
 def last_error() -> str:

@@ -135,12 +135,32 @@ Packed pack_weights(const float* flat) {
 // split-f16 packing: [dir][stream position][tile][hi|lo][lane][8 x f16], k-steps in the kernel's stream order
 struct Packed16 {
     std::vector<unsigned char> w;
+    float max_abs = 0.0f;   // largest |packed value| (after the exponent-scale fold): must stay <= 65504 to be an f16
+    bool finite = true;
+    int len_shift = 0;      // the weight row of feature 6 (event length) is stored a second time x 2^len_shift (slot 7)
 };
+
+// len_shift: the largest k <= 10 for which (length row x exponent scale x 2^k) is still an f16: an event length beyond
+// 65504 samples is then fed as v * 2^-k through slot 7 (exact power-of-two rescale; covers |v| <= 65504 * 2^k)
+int choose_len_shift(const float* flat) {
+    float m = 0.0f;
+    const float* p = flat;
+    for (int d = 0; d < 2; ++d) {
+        const float* row = p + size_t(lstm16::NFEAT - 1) * 400;            // layer-0 kernel row of feature 6
+        for (int gc = 0; gc < 400; ++gc) m = std::max(m, std::fabs(row[gc] * gate_scale(gc)));
+        p += size_t(lstm16::NFEAT + lstm16::HID) * 400 + 400 + 2 * (size_t(2 * lstm16::HID) * 400 + 400);
+    }
+    int k = 10;
+    while (k > 0 && !(m * std::ldexp(1.0f, k) <= 32768.0f)) --k;
+    return k;
+}
 
 Packed16 pack_weights_f16(const float* flat) {
     using namespace lstm16;
     Packed16 P;
     P.w.assign(size_t(2) * KS_DIR * KSTEP_BYTES, 0);
+    P.len_shift = choose_len_shift(flat);
+    const float len_mul = std::ldexp(1.0f, P.len_shift);
     const float* p = flat;
     for (int d = 0; d < 2; ++d) {
         int ks_base = 0;
@@ -159,9 +179,14 @@ Packed16 pack_weights_f16(const float* flat) {
                         for (int j = 0; j < 8; ++j) {
                             const int k = 32 * ks + 8 * (lane >> 4) + j;
                             int krow = -1;   // row of the TF kernel; -1 = zero padding
+                            float mul = 1.0f;
                             if (l == 0) {
                                 if (k < HID) krow = NFEAT + k;                                  // own h
                                 else if (k >= 8 * KG_H && k < 8 * KG_H + NFEAT) krow = k - 8 * KG_H;   // x features
+                                else if (k == 8 * KG_H + NFEAT) {                               // slot 7: length row x 2^len_shift
+                                    krow = NFEAT - 1;
+                                    mul = len_mul;
+                                }
                             } else {
                                 if (k < HID) krow = k;                                          // h of the layer below
                                 else if (k >= 8 * KG_H && k < 8 * KG_H + HID) krow = HID + (k - 8 * KG_H);   // own h
@@ -169,7 +194,9 @@ Packed16 pack_weights_f16(const float* flat) {
                             const int gc = gate_col(t, lane & 15);
                             float v = krow < 0 ? 0.0f : kern[size_t(krow) * 400 + gc];
                             if (k == own_k0 + HID) v = bias[gc] + ((gc >= 200 && gc < 300) ? 1.0f : 0.0f);   // bias row (+ forget_bias)
-                            v *= gate_scale(gc);
+                            v *= gate_scale(gc) * mul;
+                            if (!std::isfinite(v)) P.finite = false;
+                            else P.max_abs = std::max(P.max_abs, std::fabs(v));
                             const _Float16 hi = (_Float16)v;
                             const _Float16 lo = (_Float16)(v - (float)hi);
                             dst[((size_t(t) * 2 + 0) * 64 + lane) * 8 + j] = hi;
@@ -308,6 +335,10 @@ struct dm_model {
     bool profile = false;
     bool async = false;                   // DM_OPT_ASYNC: device-resident calls return after enqueue
     int precision = DM_PREC_F16X3;        // default: fastest mode that meets the 1e-4 probability tolerance
+    bool f16_ok = true;                   // every packed weight is a finite f16 (checked at create; else the default is DM_PREC_F32)
+    int len_shift = 0;                    // DM_INFO_F16_LENGTH_SHIFT
+    int* range_flag = nullptr;            // host-mapped word the f16x3 kernel sets on an input it cannot represent
+    int* d_range_flag = nullptr;          // its device address
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     double prof_ms = 0.0;
@@ -370,6 +401,10 @@ int ensure_plogit(dm_model* m, int64_t ntiles) {
 int ensure_f16(dm_model* m) {
     if (m->d_wpack16) return DM_OK;
     Packed16 P = pack_weights_f16(m->host_weights.data());
+    if (!P.finite || P.max_abs > 65504.0f)
+        return fail(DM_EINVAL, "DM_PREC_F16X3: a packed weight (|w| x exponent scale = %g) is outside the f16 range; use DM_PREC_F32",
+                    double(P.max_abs));
+    m->len_shift = P.len_shift;
     HIP_TRY(hipMalloc(&m->d_wpack16, P.w.size()));
     HIP_TRY(hipMemcpy(m->d_wpack16, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
     const float* wout = m->host_weights.data() + (DM_WEIGHT_FLOATS - 402);
@@ -429,6 +464,8 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
             if (rcp) return rcp;
         }
         p.plogit = m->d_plogit;
+        p.len_scale = std::ldexp(1.0f, -m->len_shift);
+        p.range_flag = m->d_range_flag;
         const int grid = std::min(p.dir_split ? 2 * p.ntiles : p.ntiles, m->grid_cap);
         hipLaunchKernelGGL(bilstm_f16x3_kernel, dim3(grid), dim3(THREADS), LDS_BYTES + DM16_TRACE2_LDS, m->stream, p);
         if (p.dir_split) {
@@ -475,6 +512,21 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
     return DM_OK;
 }
 
+// after the model's stream has been synchronised: did an f16x3 launch meet an input it cannot represent?
+int check_range(dm_model* m) {
+    if (m->range_flag && *reinterpret_cast<volatile int*>(m->range_flag)) {
+        *reinterpret_cast<volatile int*>(m->range_flag) = 0;
+        return fail(DM_ERANGE, "DM_PREC_F16X3: an input feature is outside the representable range (features 0-5: |x| <= 65504, "
+                    "feature 6: |x| <= 65504 * 2^%d, no NaN); the results of this call are invalid - repeat it with DM_PREC_F32",
+                    m->len_shift);
+    }
+    return DM_OK;
+}
+int sync_and_check(dm_model* m) {
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return check_range(m);
+}
+
 int predict_common(dm_model* m, const float* x, long long xstride, int64_t x_floats_total, int64_t n,
                    float* prob, uint8_t* cls, bool windows_materialised) {
     if (!m) return fail(DM_EINVAL, "null model");
@@ -488,7 +540,7 @@ int predict_common(dm_model* m, const float* x, long long xstride, int64_t x_flo
     if (xdev && pdev && cdev) {
         int rc = launch_bilstm(m, x, xstride, n, prob, cls);
         if (rc) return rc;
-        if (!m->async) HIP_TRY(hipStreamSynchronize(m->stream));
+        if (!m->async) return sync_and_check(m);
         return DM_OK;
     }
     // host buffers: stage through device memory in batches
@@ -510,7 +562,8 @@ int predict_common(dm_model* m, const float* x, long long xstride, int64_t x_flo
             if (prob && !pdev)
                 HIP_TRY(hipMemcpyAsync(prob + 2 * off, m->d_prob, sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost, m->stream));
             if (cls && !cdev) HIP_TRY(hipMemcpyAsync(cls + off, m->d_cls, cnt, hipMemcpyDeviceToHost, m->stream));
-            HIP_TRY(hipStreamSynchronize(m->stream));
+            rc = sync_and_check(m);
+            if (rc) return rc;
         }
         return DM_OK;
     }
@@ -546,7 +599,8 @@ int predict_common(dm_model* m, const float* x, long long xstride, int64_t x_flo
         if (prob && !pdev)
             HIP_TRY(hipMemcpyAsync(prob + 2 * off, m->d_prob, sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost, m->stream));
         if (cls && !cdev) HIP_TRY(hipMemcpyAsync(cls + off, m->d_cls, cnt, hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipStreamSynchronize(m->stream));
+        rc = sync_and_check(m);
+        if (rc) return rc;
     }
     return DM_OK;
 }
@@ -580,6 +634,15 @@ int model_init(dm_model* m, const float* weights) {
 #endif
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_f32_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_BYTES)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->range_flag), sizeof(int), hipHostMallocMapped));
+    *m->range_flag = 0;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_range_flag), m->range_flag, 0));
+    {   // trained kernels far outside the usual range cannot be split into f16 halves: such a model runs the fp32 kernel
+        Packed16 P16 = pack_weights_f16(weights);
+        m->f16_ok = P16.finite && P16.max_abs <= 65504.0f;
+        m->len_shift = P16.len_shift;
+        m->precision = m->f16_ok ? DM_PREC_F16X3 : DM_PREC_F32;
+    }
     return DM_OK;
 }
 
@@ -652,6 +715,7 @@ void dm_model_destroy(dm_model* m) {
     (void)hipFree(m->d_x);
     (void)hipFree(m->d_x2);
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
+    if (m->range_flag) (void)hipHostFree(m->range_flag);
     (void)hipFree(m->d_prob);
     (void)hipFree(m->d_cls);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -669,6 +733,8 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
             return DM_OK;
         case DM_OPT_PRECISION:
             if (value != DM_PREC_F32 && value != DM_PREC_F16X3) return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
+            if (value == DM_PREC_F16X3 && !m->f16_ok)
+                return fail(DM_EINVAL, "DM_PREC_F16X3 refused: a packed weight of this model is outside the f16 range (|w| x 2.886 > 65504)");
             m->precision = int(value);
             return DM_OK;
         default:
@@ -707,8 +773,18 @@ extern "C" long long dm_debug_timing(dm_model* m, unsigned long long* out, long 
 int dm_model_sync(dm_model* m) {
     if (!m) return fail(DM_EINVAL, "null model");
     HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    return DM_OK;
+    return sync_and_check(m);
+}
+
+int dm_model_get_info(dm_model* m, int key, int64_t* value) {
+    if (!m || !value) return fail(DM_EINVAL, "null argument");
+    switch (key) {
+        case DM_INFO_PRECISION: *value = m->precision; return DM_OK;
+        case DM_INFO_F16_REPRESENTABLE: *value = m->f16_ok ? 1 : 0; return DM_OK;
+        case DM_INFO_F16_LENGTH_SHIFT: *value = m->len_shift; return DM_OK;
+        case DM_INFO_DEVICE: *value = m->device; return DM_OK;
+        default: return fail(DM_EINVAL, "unknown info key %d", key);
+    }
 }
 
 int dm_profile_reset(dm_model* m) {
@@ -751,6 +827,17 @@ int dm_device_free(int device, void* p) {
 int dm_memcpy_h2d(int device, void* dst, const void* src, size_t bytes) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return DM_OK;
+}
+
+// host -> device copy queued on the model's stream, i.e. ordered with its launches: a staging buffer can be refilled for
+// the next batch without a host-side wait.  `src` must stay valid until the next dm_model_sync.
+int dm_model_h2d_async(dm_model* m, void* dst, const void* src, size_t bytes) {
+    if (!m) return fail(DM_EINVAL, "null model");
+    if (bytes == 0) return DM_OK;
+    if (!dst || !src) return fail(DM_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m->stream));
     return DM_OK;
 }
 
@@ -991,6 +1078,7 @@ struct NcclId {
 typedef int (*fn_getid)(NcclId*);
 typedef int (*fn_init)(void**, int, NcclId, int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
 typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
 struct Rccl {
@@ -998,10 +1086,12 @@ struct Rccl {
     fn_getid getid = nullptr;
     fn_init init = nullptr;
     fn_allreduce allreduce = nullptr;
+    fn_reduce reduce = nullptr;
     fn_destroy destroy = nullptr;
     fn_errstr errstr = nullptr;
 };
 Rccl g_rccl;
+constexpr int NCCL_INT32 = 2, NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_MAX = 2;   // ncclDataType_t / ncclRedOp_t values
 
 int load_rccl() {
     if (g_rccl.h) return DM_OK;
@@ -1015,14 +1105,25 @@ int load_rccl() {
     g_rccl.getid = (fn_getid)dlsym(h, "ncclGetUniqueId");
     g_rccl.init = (fn_init)dlsym(h, "ncclCommInitRank");
     g_rccl.allreduce = (fn_allreduce)dlsym(h, "ncclAllReduce");
+    g_rccl.reduce = (fn_reduce)dlsym(h, "ncclReduce");
     g_rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
     g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.getid || !g_rccl.init || !g_rccl.allreduce || !g_rccl.destroy)
+    if (!g_rccl.getid || !g_rccl.init || !g_rccl.allreduce || !g_rccl.reduce || !g_rccl.destroy)
         return fail(DM_ERCCL, "librccl is missing required symbols");
     g_rccl.h = h;
     return DM_OK;
 }
+const char* rccl_err(int e) { return g_rccl.errstr ? g_rccl.errstr(e) : "error"; }
 }  // namespace
+
+struct dm_comm {
+    int device = 0, rank = 0, nranks = 1;
+    void* comm = nullptr;          // ncclComm_t
+    hipStream_t stream = nullptr;
+    double* d_scalar = nullptr;    // one device double for barrier / max
+    int64_t reduces = 0;           // collectives issued (dm_comm_stats)
+    int64_t reduced_bytes = 0;
+};
 
 int dm_rccl_unique_id(void* out128) {
     if (!out128) return fail(DM_EINVAL, "null id buffer");
@@ -1030,28 +1131,120 @@ int dm_rccl_unique_id(void* out128) {
     if (rc) return rc;
     NcclId id;
     int e = g_rccl.getid(&id);
-    if (e) return fail(DM_ERCCL, "ncclGetUniqueId: %s", g_rccl.errstr ? g_rccl.errstr(e) : "error");
+    if (e) return fail(DM_ERCCL, "ncclGetUniqueId: %s", rccl_err(e));
     std::memcpy(out128, &id, 128);
     return DM_OK;
 }
 
-int dm_summary_reduce_rccl(dm_summary* s, const void* unique_id128, int rank, int nranks) {
-    if (!s || !unique_id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(DM_EINVAL, "bad reduce arguments");
-    int rc = load_rccl();
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(s->device));
+dm_comm* dm_comm_create(int device, const void* unique_id128, int rank, int nranks) {
+    if (!unique_id128 || nranks < 1 || rank < 0 || rank >= nranks) {
+        fail(DM_EINVAL, "bad communicator arguments (rank %d of %d)", rank, nranks);
+        return nullptr;
+    }
+    if (load_rccl() != DM_OK) return nullptr;
+    dm_comm* c = new (std::nothrow) dm_comm();
+    if (!c) {
+        fail(DM_ENOMEM, "out of host memory");
+        return nullptr;
+    }
+    c->device = device;
+    c->rank = rank;
+    c->nranks = nranks;
     NcclId id;
     std::memcpy(&id, unique_id128, 128);
-    void* comm = nullptr;
-    int e = g_rccl.init(&comm, nranks, id, rank);
-    if (e) return fail(DM_ERCCL, "ncclCommInitRank: %s", g_rccl.errstr ? g_rccl.errstr(e) : "error");
-    if (s->follow) (void)hipStreamSynchronize(s->follow->stream);   // adds queued on the classifier's stream
-    // one in-place sum over touch|cov|mod (int32 = ncclInt32 (2), ncclSum (0)); integer sum is order independent
-    e = g_rccl.allreduce(s->d_counts, s->d_counts, size_t(3) * s->length, 2, 0, comm, s->stream);
-    hipError_t he = hipStreamSynchronize(s->stream);
-    g_rccl.destroy(comm);
-    if (e) return fail(DM_ERCCL, "ncclAllReduce: %s", g_rccl.errstr ? g_rccl.errstr(e) : "error");
-    if (he != hipSuccess) return fail(DM_EDEVICE, "stream sync after all-reduce: %s", hipGetErrorString(he));
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc(&c->d_scalar, sizeof(double)) == hipSuccess;
+    if (!ok) {
+        fail(DM_EDEVICE, "communicator setup on device %d failed: %s", device, hipGetErrorString(hipGetLastError()));
+        dm_comm_destroy(c);
+        return nullptr;
+    }
+    int e = g_rccl.init(&c->comm, nranks, id, rank);       // collective over all ranks: every rank calls it once
+    if (e) {
+        fail(DM_ERCCL, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, rccl_err(e));
+        c->comm = nullptr;
+        dm_comm_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void dm_comm_destroy(dm_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) g_rccl.destroy(c->comm);
+    (void)hipFree(c->d_scalar);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dm_comm_rank(const dm_comm* c) { return c ? c->rank : -1; }
+int dm_comm_size(const dm_comm* c) { return c ? c->nranks : 0; }
+
+int dm_comm_stats(const dm_comm* c, int64_t* collectives, int64_t* bytes) {
+    if (!c) return fail(DM_EINVAL, "null communicator");
+    if (collectives) *collectives = c->reduces;
+    if (bytes) *bytes = c->reduced_bytes;
+    return DM_OK;
+}
+
+// max over ranks of *value (in place); with value == NULL a plain barrier.  Host-synchronous.
+int dm_comm_max_f64(dm_comm* c, double* value) {
+    if (!c) return fail(DM_EINVAL, "null communicator");
+    HIP_TRY(hipSetDevice(c->device));
+    double v = value ? *value : 0.0;
+    HIP_TRY(hipMemcpyAsync(c->d_scalar, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
+    int e = g_rccl.allreduce(c->d_scalar, c->d_scalar, 1, NCCL_FLOAT64, NCCL_MAX, c->comm, c->stream);
+    if (e) return fail(DM_ERCCL, "ncclAllReduce(max): %s", rccl_err(e));
+    HIP_TRY(hipMemcpyAsync(&v, c->d_scalar, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (value) *value = v;
+    return DM_OK;
+}
+int dm_comm_barrier(dm_comm* c) { return dm_comm_max_f64(c, nullptr); }
+
+// In-place sum of touch|cov|mod over the ranks of `c` (int32, order independent -> the BED is the same for any sharding):
+// root >= 0: ncclReduce, the result is valid on `root` only (what the final per-position summary needs);
+// root < 0 : ncclAllReduce, valid everywhere.  All ranks must call it for summaries of the same length, in the same order.
+int dm_summary_reduce(dm_summary* s, dm_comm* c, int root) {
+    if (!s || !c) return fail(DM_EINVAL, "null summary / communicator");
+    if (root >= c->nranks) return fail(DM_EINVAL, "root %d outside the %d ranks", root, c->nranks);
+    if (s->device != c->device) return fail(DM_EINVAL, "summary on device %d, communicator on device %d", s->device, c->device);
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->follow) HIP_TRY(hipStreamSynchronize(s->follow->stream));   // adds queued on the classifier's stream
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const size_t count = size_t(3) * s->length;
+    int e = root >= 0 ? g_rccl.reduce(s->d_counts, s->d_counts, count, NCCL_INT32, NCCL_SUM, root, c->comm, c->stream)
+                      : g_rccl.allreduce(s->d_counts, s->d_counts, count, NCCL_INT32, NCCL_SUM, c->comm, c->stream);
+    if (e) return fail(DM_ERCCL, "%s: %s", root >= 0 ? "ncclReduce" : "ncclAllReduce", rccl_err(e));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ++c->reduces;
+    c->reduced_bytes += int64_t(count) * 4;
+    return DM_OK;
+}
+
+// Grow the counters to `new_length` positions (new positions zero).  A worker that learns contig lengths from its reads
+// sizes the counters as it goes; before a reduce all ranks grow to the common length.
+int dm_summary_grow(dm_summary* s, int64_t new_length) {
+    if (!s) return fail(DM_EINVAL, "null summary");
+    if (new_length <= s->length) return DM_OK;
+    if (new_length > (int64_t(1) << 33)) return fail(DM_EINVAL, "bad contig length %lld", (long long)new_length);
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->follow) HIP_TRY(hipStreamSynchronize(s->follow->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    int* nd = nullptr;
+    if (hipMalloc(&nd, sizeof(int) * 3 * new_length) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DM_ENOMEM, "cannot grow the summary to %lld positions", (long long)new_length);
+    }
+    HIP_TRY(hipMemsetAsync(nd, 0, sizeof(int) * 3 * new_length, s->stream));
+    for (int k = 0; k < 3; ++k)
+        HIP_TRY(hipMemcpyAsync(nd + k * new_length, s->d_counts + k * s->length, sizeof(int) * s->length, hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipFree(s->d_counts));
+    s->d_counts = nd;
+    s->length = new_length;
     return DM_OK;
 }
 

@@ -6,6 +6,12 @@ function names, argument meaning and side effects, driving the HIP library inste
     sum_handler      myDetect.py:1028-1120 per (chr, strand) coverage / mod-count summary -> BED
     mDetect_manager  myDetect.py:1124-1263 sharding, worker processes, index merge, .done marker
 
+Two run modes behind `mDetect_manager` (deepmod_amd/stream.py has the first):
+  * streaming (default): one process per GPU keeps the per-position counters on the device, classifier output goes
+    straight into them, one RCCL reduce per contig x strand at the end, rank 0 writes the BED files; no per-read files;
+  * stored (`--storePred 1`, and the `--predDet 0` resume): the reference's file shape - per-read prediction tables and
+    per-chromosome index files written by the detect workers, read back by the summary workers.
+
 Inputs are containers instead of .fast5 files (no h5py / libhdf5 in this image): *raw containers*
 (deepmod_amd/rawreads.py: DAC samples + basecaller events; normalised on the GPU, aligned with the SAM
 records, mapped by dm_map_read) or *feature containers* (deepmod_amd/predstore.py: per-read `mfeatures`,
@@ -123,22 +129,39 @@ def mPredict_batch(moptions, sp_options, reads):
 # ---------------------------------------------------------------------------------------------
 # worker
 # ---------------------------------------------------------------------------------------------
+_PREDICT_ERRORS = (IndexError, ValueError, KeyError)     # malformed read tables; anything else is a bug and propagates
+
+
+def _predict_reads(moptions, sp_options, good, src):
+    """-> [pred_mod_num or None (failed)] for a group of reads.  One device call for the whole group (mPredict_batch);
+    if a read's tables are malformed the group is redone read by read so that only the offending read is skipped and
+    recorded - the reference's granularity (mPredict1 per read inside handle_record's try, myDetect.py:715)."""
+    sess = sp_options['rnn'][0]
+    per_read = lambda rd: mPredict1(moptions, sp_options, {'f5data': {rd['readk']: (None, rd['events'], None, src)}},
+                                    rd['mfeatures'], rd['base_map_info'], rd['readk'], rd['start_clip'], rd['end_clip'])
+    if hasattr(sess, 'model') and getattr(sess, 'model') is not None:
+        try:
+            return mPredict_batch(moptions, sp_options, good)
+        except _PREDICT_ERRORS:
+            for rd in good:
+                rd['base_map_info']['mod_pred'] = 0      # a partial scatter of the failed batch call must not survive
+    out = []
+    for rd in good:
+        try:
+            out.append(per_read(rd))
+        except _PREDICT_ERRORS as exc:
+            sp_options["Error"]["Prediction failed: %s" % type(exc).__name__].append(rd.get('src', src))
+            out.append(None)
+    return out
+
+
 def _predict_and_store(moptions, sp_options, store, good, src):
-    """mPredict1 for a group of reads (one device call), prediction tables and index entries (myDetect.py:715-718)."""
+    """Prediction, prediction tables and index entries of a group of reads (myDetect.py:715-718)."""
     if not good:
         return
-    try:      # one device call for all reads of the group (see mPredict_batch)
-        sess = sp_options['rnn'][0]
-        if hasattr(sess, 'model') and getattr(sess, 'model') is not None:
-            pred_nums = mPredict_batch(moptions, sp_options, good)
-        else:
-            pred_nums = [mPredict1(moptions, sp_options, {'f5data': {rd['readk']: (None, rd['events'], None, src)}},
-                                   rd['mfeatures'], rd['base_map_info'], rd['readk'], rd['start_clip'], rd['end_clip'])
-                         for rd in good]
-    except Exception as exc:  # same (reason -> files) error channel as the reference
-        sp_options["Error"]["Prediction failed: %s" % type(exc).__name__].append(src)
-        return
-    for rd, pred_mod_num in zip(good, pred_nums):
+    for rd, pred_mod_num in zip(good, _predict_reads(moptions, sp_options, good, src)):
+        if pred_mod_num is None:
+            continue
         rsrc = rd.get('src', src)
         key = store.add(rd, rd['base_map_info'], pred_mod_num, rsrc, moptions)
         sp_options['Mod'].append([rd['chr'], rd['strand'], rd['mapped_start'], key,
@@ -179,7 +202,7 @@ def _alignment_lines(moptions, sp_options, raw_files, f5data):
 def mDetect1_raw(moptions, sp_options, store, raw_files):
     """The reference's mDetect1 for raw reads (myDetect.py:392-465): signal -> events (GPU normalisation and event
     statistics) -> alignment records -> base_map_info + features -> prediction."""
-    f5data = rawreads.get_Event_Signals(moptions, sp_options, raw_files)
+    f5data = rawreads.get_Event_Signals(moptions, sp_options, raw_files, sp_options.get('normalizer'))
     if not f5data:
         return
     align_info = _alignment_lines(moptions, sp_options, raw_files, f5data)
@@ -232,63 +255,82 @@ def mDetect1(moptions, sp_options, container_files):
                 fh.write(' '.join([str(v) for v in mfi] + ['\n']))
 
 
-def detect_handler(moptions, h5files_Q, failed_Q, file_map_info_q, device=0):
-    """Worker process: one model on one GPU, pulls (files, ctfolderid, batchid) until the queue is
-    empty (myDetect.py:948-984)."""
-    from . import model as dm
-    _, init_l, _, _, _, X, Y, _, _, _, _, mfpred = dm.mCreateSession(moptions['fnum'], moptions['hidden'],
-                                                                     moptions['windowsize'], moptions)
-    sess = dm.new_session(device)
-    new_saver = dm.import_meta_graph(moptions['modfile'][0] + '.meta')
-    new_saver.restore(sess, dm.latest_checkpoint(moptions['modfile'][1]) or moptions['modfile'][0])
+class _StoreWorker:
+    """One detect worker of the stored mode: a model and a signal normaliser on its GPU, processes work items
+    (files, sub-folder id, batch id) into `<out>/<sub-folder>/rnn.pred.detail.npz.<batch>` + per-chromosome index files."""
 
-    while not h5files_Q.empty():
-        cur_start_time = time.time()
-        try:
-            f5files, ctfolderid, batchid = h5files_Q.get(block=False)
-        except Exception:
-            break
-        sp_options = defaultdict()
-        sp_options['ctfolderid'] = ctfolderid
-        sp_options['ctfolder'] = moptions['outFolder'] + moptions['FileID'] + '/' + str(ctfolderid)
-        os.makedirs(sp_options['ctfolder'], exist_ok=True)
-        sp_options['rnn'] = (sess, X, Y, init_l, mfpred)
-        sp_options['batchid'] = batchid
-        sp_options['Mod'] = []
-        sp_options['Error'] = defaultdict(list)
-        mDetect1(moptions, sp_options, f5files)
-        for errtype, errfiles in sp_options["Error"].items():
-            failed_Q.put((errtype, errfiles))
-        if moptions.get('outLevel', OUTPUT_WARNING) <= OUTPUT_INFO:
-            print("Cur Prediction consuming time %d for %d %d" % (time.time() - cur_start_time, ctfolderid, batchid))
-    sess.close()
+    def __init__(self, moptions, device):
+        from . import model as dm, signal as dmsignal
+        handles = dm.mCreateSession(moptions['fnum'], moptions['hidden'], moptions['windowsize'], moptions)
+        self.tokens = (handles[5], handles[6], handles[1], handles[11])          # X, Y, init_l, mfpred
+        self.sess = dm.new_session(device)
+        dm.import_meta_graph(moptions['modfile'][0] + '.meta').restore(
+            self.sess, dm.latest_checkpoint(moptions['modfile'][1]) or moptions['modfile'][0])
+        self.normalizer = dmsignal.SignalNormalizer(device)       # signal stage on the worker's own GPU
+        self.moptions = moptions
+
+    def process(self, files, subfolder, batchid):
+        mo = self.moptions
+        X, Y, init_l, mfpred = self.tokens
+        folder = '%s%s/%d' % (mo['outFolder'], mo['FileID'], subfolder)
+        os.makedirs(folder, exist_ok=True)
+        sp_options = {'ctfolderid': subfolder, 'ctfolder': folder, 'batchid': batchid, 'Mod': [],
+                      'rnn': (self.sess, X, Y, init_l, mfpred), 'Error': defaultdict(list), 'normalizer': self.normalizer}
+        mDetect1(mo, sp_options, files)
+        return sp_options['Error']
+
+    def close(self):
+        self.normalizer.close()
+        self.sess.close()
+
+
+def _take(work_q):
+    """Next item of a shared work queue, None when it is drained."""
+    try:
+        return work_q.get(block=False)
+    except Exception:
+        return None
+
+
+def detect_handler(moptions, h5files_Q, failed_Q, file_map_info_q, device=0):
+    """Detect worker process of the stored mode, the reference's entry point (myDetect.py:948-984): one model per
+    process, work items taken from `h5files_Q` until it is drained, (reason, files) pairs posted to `failed_Q`."""
+    worker = _StoreWorker(moptions, device)
+    verbose = moptions.get('outLevel', OUTPUT_WARNING) <= OUTPUT_INFO
+    item = _take(h5files_Q)
+    while item is not None:
+        t0 = time.time()
+        files, subfolder, batchid = item
+        for reason, where in worker.process(files, subfolder, batchid).items():
+            failed_Q.put((reason, where))
+        if verbose:
+            print("Cur Prediction consuming time %d for %d %d" % (time.time() - t0, subfolder, batchid))
+        item = _take(h5files_Q)
+    worker.close()
 
 
 # ---------------------------------------------------------------------------------------------
 # summary
 # ---------------------------------------------------------------------------------------------
 def read_file_list(cur_cif, cur_chr, cur_strand, sp_options):
-    """Index-file reader, same format as the reference (myDetect.py:989-1008)."""
-    cur_list = []
-    with open(cur_cif, 'r') as mr:
-        for line in mr:
-            line = line.strip()
-            if not line:
+    """Index file `rnn.pred.ind.<chr>` -> sp_options['handlingList'] (records of `cur_strand`) and the two base folders
+    of its header (format written by merge_index_files / the reference, myDetect.py:1194-1221; reader :989-1008)."""
+    header_keys = {'#base_folder_fast5': 'base_folder_fast5', '#base_folder_output': 'base_folder_output'}
+    records = []
+    with open(cur_cif) as fh:
+        for fields in (ln.split() for ln in fh):
+            if not fields:
                 continue
-            lsp = line.split()
-            if line[0] == '#':
-                if lsp[1][-1] not in ['/', '\\']:
-                    lsp[1] = lsp[1] + '/'
-                if lsp[0] == '#base_folder_fast5':
-                    sp_options['base_folder_fast5'] = lsp[1]
-                elif lsp[0] == '#base_folder_output':
-                    sp_options['base_folder_output'] = lsp[1]
-            else:
-                if lsp[1] == cur_strand:
-                    cur_list.append(lsp)
-                if not lsp[0] == cur_chr:
-                    print('Warning!!! The chr should be %s but %s is found.' % (cur_chr, lsp[0]))
-    sp_options['handlingList'] = cur_list
+            if fields[0].startswith('#'):
+                folder = fields[1] if fields[1].endswith(('/', '\\')) else fields[1] + '/'
+                if fields[0] in header_keys:
+                    sp_options[header_keys[fields[0]]] = folder
+                continue
+            if fields[0] != cur_chr:
+                print('Warning!!! The chr should be %s but %s is found.' % (cur_chr, fields[0]))
+            if fields[1] == cur_strand:
+                records.append(fields)
+    sp_options['handlingList'] = records
 
 
 def read_pred_detail(moptions, sp_options, f5info):
@@ -306,11 +348,29 @@ def base_flags(m_pred, base: str) -> np.ndarray:
     return (is_base.astype(np.uint8) | (not_gap.astype(np.uint8) << 1) | (is_mod.astype(np.uint8) << 2))
 
 
-def summarize_tables(tables, base: str, device: int = 0, length=None):
-    """Accumulate an iterable of prediction tables on the GPU -> (touch, cov, mod) int32 arrays."""
+def summarize_tables(tables, base: str, device: int = 0, length=None, chunk_rows: int = 4_000_000):
+    """Accumulate an iterable of prediction tables on the GPU -> (touch, cov, mod) int32 arrays.  Rows are shipped in
+    chunks of ~chunk_rows (a human chromosome at 30x is ~1e10 table rows: never held on the host at once); without a
+    known length the counters grow as the tables reach further."""
     from . import summary
-    pos_parts, flag_parts = [], []
-    maxpos = -1
+    summ = None
+    pend_p, pend_f, pending = [], [], 0
+
+    def flush():
+        nonlocal summ, pend_p, pend_f, pending
+        if not pending:
+            return
+        p, f = np.concatenate(pend_p), np.concatenate(pend_f)
+        need = int(p.max()) + 1
+        if summ is None:
+            summ = summary.PositionSummary(length if length else need, device)
+        elif need > summ.length:
+            if length:
+                raise IndexError('position %d outside the %d positions of the contig' % (need - 1, length))
+            summ.grow(int(need * 1.5))
+        summ.add(p, f)
+        pend_p, pend_f, pending = [], [], 0
+
     for m_pred in tables:
         if len(m_pred) == 0:
             continue
@@ -318,21 +378,21 @@ def summarize_tables(tables, base: str, device: int = 0, length=None):
         keep = (fl & 1) != 0
         if not keep.any():
             continue
-        p = m_pred['refbasei'][keep].astype(np.int64)
-        pos_parts.append(p)
-        flag_parts.append(fl[keep])
-        maxpos = max(maxpos, int(p.max()))
-    if length is None:
-        length = maxpos + 1
-    if length <= 0:
-        z = np.zeros(0, np.int32)
+        pend_p.append(m_pred['refbasei'][keep].astype(np.int64))
+        pend_f.append(fl[keep])
+        pending += int(keep.sum())
+        if pending >= chunk_rows:
+            flush()
+    flush()
+    if summ is None:
+        z = np.zeros(max(int(length or 0), 0), np.int32)
         return z, z.copy(), z.copy()
-    summ = summary.PositionSummary(length, device)
-    if pos_parts:
-        summ.add(np.concatenate(pos_parts), np.concatenate(flag_parts))
-    out = summ.fetch()
+    touch, cov, mod = summ.fetch()
     summ.close()
-    return out
+    if not length:      # trim the growth slack: positions past the last touched one carry nothing
+        last = int(np.flatnonzero(touch).max()) + 1 if touch.any() else 0
+        touch, cov, mod = touch[:last], cov[:last], mod[:last]
+    return touch, cov, mod
 
 
 def sum_handler(moptions, chr_strand_Q, device=0):
@@ -372,122 +432,183 @@ def sum_handler(moptions, chr_strand_Q, device=0):
 # ---------------------------------------------------------------------------------------------
 # manager
 # ---------------------------------------------------------------------------------------------
+SUBFOLDER_BATCHES = 100     # a new output sub-folder every 100 batches (myDetect.py:1161, :1168-1169)
+
+
+def discover_inputs(wrk_base, recursive):
+    """Containers under the working folder, optionally up to three levels down, sorted."""
+    found = []
+    levels = ['', '*/', '*/*/', '*/*/*/'] if recursive else ['']
+    for suffix in (predstore.CONTAINER_SUFFIX, rawreads.RAW_SUFFIX):
+        for lv in levels:
+            found.extend(glob.glob(os.path.join(wrk_base, lv + '*' + suffix)))
+    return sorted(found)
+
+
+def plan_batches(files, per_batch):
+    """[(files, sub-folder id, batch id)]: consecutive groups of `per_batch` inputs - the work items of the reference's
+    h5files_Q (myDetect.py:1160-1172)."""
+    return [(files[i:i + per_batch], (i // per_batch) // SUBFOLDER_BATCHES, i // per_batch)
+            for i in range(0, len(files), per_batch)]
+
+
+def _run_processes(ctx, target, argsets, what, poll=None):
+    """Start one process per argument tuple, call `poll()` while they run, fail loudly if one dies."""
+    procs = [ctx.Process(target=target, args=a) for a in argsets]
+    for p in procs:
+        p.start()
+    while any(p.is_alive() for p in procs):
+        if poll is None or not poll():
+            time.sleep(0.02)
+    for p in procs:
+        p.join()
+    if any(p.exitcode != 0 for p in procs):
+        raise RuntimeError('a %s worker died: exit codes %s' % (what, [p.exitcode for p in procs]))
+
+
+def _report_errors(ledger):
+    if ledger:
+        print('Error information for different fast5 files:')
+        for reason, files in ledger.items():
+            print('\t' + reason, len(files))
+
+
+def merge_index_files(out_root, wrk_base):
+    """Per-batch `<chr>.rnn.pred.ind.<batch>` files of all sub-folders -> one sorted `rnn.pred.ind.<chr>` per chromosome
+    with the two `#base_folder_*` header lines (byte format of myDetect.py:1194-1221; every line ends with ' ' + newline)."""
+    per_chr = defaultdict(list)
+    for path in glob.glob(os.path.join(out_root, '*', '*.' + pre_base_str + '.*')):
+        per_chr[os.path.basename(path).split('.' + pre_base_str)[0]].append(path)
+    for chrom, paths in per_chr.items():
+        records = []
+        for path in paths:
+            with open(path) as fh:
+                for fields in (ln.split() for ln in fh):
+                    if fields:
+                        records.append(fields[:2] + [int(fields[2])] + fields[3:])
+        records.sort()                     # (chr, strand, mapped start, key, ...)
+        lines = [['#base_folder_fast5', wrk_base], ['#base_folder_output', os.path.abspath(out_root)]] + records
+        with open(os.path.join(out_root, pre_base_str + '.' + chrom), 'w') as fh:
+            fh.writelines(' '.join(str(v) for v in rec) + ' \n' for rec in lines)
+
+
+def _run_stored_detect(moptions, ctx, pmanager, items, ngpu):
+    work_q, failed_q, info_q = pmanager.Queue(), pmanager.Queue(), pmanager.Queue()
+    for it in items:
+        work_q.put(it)
+    ledger = defaultdict(list)
+
+    def poll():
+        try:
+            reason, files = failed_q.get(block=False)
+        except Exception:
+            return False
+        ledger[reason].extend(files)
+        return True
+
+    _run_processes(ctx, _worker_entry, [(detect_handler, (moptions, work_q, failed_q, info_q), w % ngpu)
+                                        for w in range(moptions['threads'])], 'detect', poll)
+    while poll():
+        pass
+    merge_index_files(moptions['outFolder'] + moptions['FileID'], moptions['wrkBase'])
+    return ledger
+
+
+def _run_streaming_detect(moptions, ctx, pmanager, items, ngpu):
+    """One process per GPU (rank), work items pulled from one shared queue by all ranks, counters merged with RCCL
+    (deepmod_amd/stream.py).  -> (error ledger, per-rank stats)"""
+    from . import stream
+    world = max(1, min(ngpu, len(items)))
+    work_q, result_q = pmanager.Queue(), pmanager.Queue()
+    for it in items:
+        work_q.put(it)
+    run_opts = dict(moptions, outFolder=moptions['outFolder'] + moptions['FileID'])
+    rdv = os.path.join(run_opts['outFolder'], '.rendezvous')
+    if os.path.isdir(rdv):
+        for f in os.listdir(rdv):
+            os.remove(os.path.join(rdv, f))
+    feeders = max(1, moptions['threads'] // world)
+    _run_processes(ctx, stream.stream_rank_main, [(run_opts, r, world, r, work_q, result_q, feeders) for r in range(world)],
+                   'streaming detect')
+    ledger, stats = defaultdict(list), []
+    while True:
+        try:
+            res = result_q.get(block=False)
+        except Exception:
+            break
+        for reason, files in res['errors'].items():
+            ledger[reason].extend(files)
+        stats.append(res['stats'])
+    if len(stats) != world:
+        raise RuntimeError('streaming detect: %d of %d ranks reported' % (len(stats), world))
+    return ledger, stats
+
+
+def _print_stream_stats(stats, wall):
+    tot = defaultdict(float)
+    for st in stats:
+        for k, v in st.items():
+            tot[k] += v
+    rows = tot['windows']
+    print('Streaming detect: %d reads, %d base-positions classified on %d GPU(s) in %.1f s = %.3g base-positions/s'
+          % (tot['reads'], rows, len(stats), wall, rows / max(wall, 1e-9)))
+    host = {k[5:]: v for k, v in tot.items() if k.startswith('prep_')}
+    busy = sum(host.values()) + tot['submit']
+    parts = ['%s %.0f%%' % (k, 100 * v / max(busy, 1e-9)) for k, v in sorted(host.items(), key=lambda kv: -kv[1])]
+    print('\thost stages (share of feeder + submit time): ' + ', '.join(parts) + ', device submit %.0f%%' % (100 * tot['submit'] / max(busy, 1e-9))
+          + '; detect wall %.1f s, waiting for feeders %.1f s, merge + BED %.1f s per rank'
+          % (tot['detect_wall'] / len(stats), tot['wait_feed'] / len(stats), tot['merge+bed'] / len(stats)))
+
+
+def _run_summary_jobs(moptions, ctx, pmanager, ngpu):
+    """One job per index file x strand, `threads` summary workers (myDetect.py:1232-1252)."""
+    index_files = sorted(glob.glob(os.path.join(moptions['predpath'], pre_base_str + '.*')))
+    print('Find: %s %d %s' % (moptions['predpath'], len(index_files), pre_base_str))
+    job_q = pmanager.Queue()
+    for path in index_files:
+        chrom = os.path.basename(path)[len(pre_base_str) + 1:]
+        for strand in '+-':
+            job_q.put((path, chrom, strand))
+    nworkers = min(moptions['threads'], 2 * len(index_files))
+    _run_processes(ctx, _worker_entry, [(sum_handler, (moptions, job_q), w % ngpu) for w in range(nworkers)], 'summary')
+
+
 def _worker_entry(target, args, device):
     target(*args, device=device)
 
 
 def mDetect_manager(moptions):
-    """Same orchestration shape as the reference (myDetect.py:1124-1263): batches of
-    `files_per_thread` inputs, `threads` worker processes (round-robin over the visible GPUs), per-chr
-    index merge, one summary job per chr x strand, `<outFolder>.done` marker."""
-    ctx = multiprocessing.get_context('spawn')   # never fork a process that may hold a HIP context
+    """The detect run (counterpart of myDetect.py:1124-1263): inputs -> worker batches -> detect -> per-position summary
+    -> `<outFolder>.done`.  predDet == 1 runs the streaming mode unless `storePred` asks for the reference's per-read
+    files; predDet == 0 summarises the stored predictions under `predpath` (bin/DeepMod.py:143-148)."""
+    ctx = multiprocessing.get_context('spawn')      # never fork a process that may hold a HIP context
     pmanager = ctx.Manager()
-    while moptions.get('wrkBase') and moptions['wrkBase'][-1] in ['/', '\\']:
-        moptions['wrkBase'] = moptions['wrkBase'][:-1]
     ngpu = max(1, int(moptions.get('gpus', 1)))
-
+    moptions['threads'] = max(1, int(moptions['threads']))
+    if moptions.get('wrkBase'):
+        moptions['wrkBase'] = moptions['wrkBase'].rstrip('/\\') or moptions['wrkBase']
+    streamed = False
     if moptions['predDet'] == 1:
-        if moptions['modfile'].rfind('/') == -1:
-            moptions['modfile'] = [moptions['modfile'], './']
+        t0 = time.time()
+        cut = moptions['modfile'].rfind('/')
+        moptions['modfile'] = [moptions['modfile'], './' if cut == -1 else moptions['modfile'][:cut + 1]]
+        files = discover_inputs(moptions['wrkBase'], moptions['recursive'] == 1)
+        print('Total files=%d' % len(files))
+        out_root = moptions['outFolder'] + moptions['FileID']
+        os.makedirs(out_root, exist_ok=True)
+        items = plan_batches(files, moptions['files_per_thread'])
+        streamed = not moptions.get('storePred', 0)
+        if streamed:
+            ledger, stats = _run_streaming_detect(moptions, ctx, pmanager, items, ngpu)
+            _print_stream_stats(stats, time.time() - t0)
         else:
-            moptions['modfile'] = [moptions['modfile'], moptions['modfile'][:moptions['modfile'].rfind('/') + 1]]
-        start_time = time.time()
-        f5files = []
-        for pat in ('*' + predstore.CONTAINER_SUFFIX, '*' + rawreads.RAW_SUFFIX):
-            f5files.extend(glob.glob(os.path.join(moptions['wrkBase'], pat)))
-            if moptions['recursive'] == 1:
-                for depth in ('*/', '*/*/', '*/*/*/'):
-                    f5files.extend(glob.glob(os.path.join(moptions['wrkBase'], depth + pat)))
-        f5files = sorted(f5files)
-        print('Total files=%d' % len(f5files))
-        os.makedirs(moptions['outFolder'] + moptions['FileID'], exist_ok=True)
-
-        h5files_Q = pmanager.Queue()
-        file_map_info_q = pmanager.Queue()
-        failed_Q = pmanager.Queue()
-        h5_batch = []
-        h5batchind = 0
-        sub_folder_size = 100
-        sub_folder_id = 0
-        for f5f in f5files:
-            h5_batch.append(f5f)
-            if len(h5_batch) == moptions['files_per_thread']:
-                h5files_Q.put((h5_batch, sub_folder_id, h5batchind))
-                h5_batch = []
-                h5batchind += 1
-                if h5batchind % sub_folder_size == 0:
-                    sub_folder_id += 1
-        if len(h5_batch) > 0:
-            h5files_Q.put((h5_batch, sub_folder_id, h5batchind))
-            h5batchind += 1
-
-        share_var = (moptions, h5files_Q, failed_Q, file_map_info_q)
-        handlers = []
-        for hid in range(moptions['threads']):
-            p = ctx.Process(target=_worker_entry, args=(detect_handler, share_var, hid % ngpu))
-            p.start()
-            handlers.append(p)
-        failed_files = defaultdict(list)
-        while any(p.is_alive() for p in handlers):
-            try:
-                errk, fns = failed_Q.get(block=False)
-                failed_files[errk].extend(fns)
-            except Exception:
-                time.sleep(0.05)
-        while not failed_Q.empty():
-            errk, fns = failed_Q.get(block=False)
-            failed_files[errk].extend(fns)
-        if any(p.exitcode != 0 for p in handlers):
-            raise RuntimeError('a detect worker died: exit codes %s' % [p.exitcode for p in handlers])
-
-        # merge per-batch index files -> rnn.pred.ind.<chr>, sorted (myDetect.py:1194-1221)
-        moptions['predpath'] = moptions['outFolder'] + '/' + moptions['FileID']
-        pred_ind_pref = moptions['outFolder'] + '/' + moptions['FileID'] + '/' + pre_base_str
-        pred_chr_files = glob.glob(os.path.join(moptions['outFolder'] + moptions['FileID'], '*/*.' + pre_base_str + '.*'))
-        chr_dict = defaultdict(list)
-        for pcf in pred_chr_files:
-            chr_dict[pcf.split('/')[-1].split('.' + pre_base_str)[0]].append(pcf)
-        for ck in chr_dict:
-            cur_list = [['#base_folder_fast5', moptions['wrkBase']],
-                        ['#base_folder_output', os.path.abspath(moptions['outFolder'] + moptions['FileID'])]]
-            for sub_c_f in chr_dict[ck]:
-                with open(sub_c_f, 'r') as mr:
-                    for line in mr:
-                        line = line.strip()
-                        if len(line) > 0:
-                            lsp = line.split()
-                            lsp[2] = int(lsp[2])
-                            cur_list.append(lsp)
-            cur_list = sorted(cur_list)   # '#...' header rows sort first, records by (chr, strand, start, key)
-            with open(pred_ind_pref + '.' + ck, 'w') as indf_writer:
-                for mfi in cur_list:
-                    indf_writer.write(' '.join([str(v) for v in mfi] + ['\n']))
-        if len(failed_files) > 0:
-            print('Error information for different fast5 files:')
-            for errtype, errfiles in failed_files.items():
-                print('\t' + errtype, len(errfiles))
-        moptions['outFolder'] = moptions['outFolder'] + moptions['FileID']
-        print("Per-read Prediction consuming time %d" % (time.time() - start_time))
-
-    # ---- summary phase (also the --predDet 0 --predpath resume path, DeepMod.py:143-148)
-    start_time = time.time()
-    all_chr_ind_files = sorted(glob.glob(os.path.join(moptions['predpath'], pre_base_str + '.*')))
-    print('Find: %s %d %s' % (moptions['predpath'], len(all_chr_ind_files), pre_base_str))
-    chr_strand_Q = pmanager.Queue()
-    jobnum = 0
-    for cur_cif in all_chr_ind_files:
-        chrname = cur_cif.split(pre_base_str)[-1][1:]
-        chr_strand_Q.put((cur_cif, chrname, '+'))
-        chr_strand_Q.put((cur_cif, chrname, '-'))
-        jobnum += 2
-    handlers = []
-    for hid in range(min(moptions['threads'], jobnum)):
-        p = ctx.Process(target=_worker_entry, args=(sum_handler, (moptions, chr_strand_Q), hid % ngpu))
-        p.start()
-        handlers.append(p)
-    for p in handlers:
-        p.join()
-    if any(p.exitcode != 0 for p in handlers):
-        raise RuntimeError('a summary worker died: exit codes %s' % [p.exitcode for p in handlers])
-    print("Genomic-position Detection consuming time %d" % (time.time() - start_time))
+            ledger = _run_stored_detect(moptions, ctx, pmanager, items, ngpu)
+            moptions['predpath'] = moptions['outFolder'] + '/' + moptions['FileID']
+        _report_errors(ledger)
+        moptions['outFolder'] = out_root
+        print("Per-read Prediction consuming time %d" % (time.time() - t0))
+    if not streamed:
+        t0 = time.time()
+        _run_summary_jobs(moptions, ctx, pmanager, ngpu)
+        print("Genomic-position Detection consuming time %d" % (time.time() - t0))
     open(moptions['outFolder'] + '.done', 'a').close()

@@ -141,6 +141,19 @@ class BiLSTMModel:
     def sync(self):
         _lib.check(self._lib.dm_model_sync(self._h))
 
+    def get_info(self, key: int) -> int:
+        v = ctypes.c_int64()
+        _lib.check(self._lib.dm_model_get_info(self._h, key, ctypes.byref(v)))
+        return v.value
+
+    def upload_async(self, dst_ptr: int, arr: np.ndarray):
+        """Host array -> device address, queued on the model's stream (keep `arr` alive until the next sync())."""
+        _lib.check(self._lib.dm_model_h2d_async(self._h, dst_ptr, arr.ctypes.data, arr.nbytes))
+
+    def predict_rows_device(self, rows_ptr: int, m_rows: int, first: int, count: int, cls_ptr: int, prob_ptr=None):
+        """dm_predict_read on raw device addresses (staging buffers of the streaming worker)."""
+        _lib.check(self._lib.dm_predict_read(self._h, rows_ptr, m_rows, first, count, prob_ptr, cls_ptr))
+
     # -- inference ------------------------------------------------------------------------
     def predict_windows(self, x, prob=None, cls=None, want_prob: bool = True):
         """x: float[n,21,7] numpy (any float dtype; cast to fp32 like the TF placeholder feed) or a

@@ -65,6 +65,8 @@ def save_feature_container(path: str, reads: List[Dict]) -> None:
 
 def load_feature_container(path: str) -> List[Dict]:
     z = np.load(path, allow_pickle=False)
+    if 'format' in z.files and int(z['format']) == 2:
+        return _classic_reads(load_packed(path))
     metas = json.loads(str(z['meta']))
     reads = []
     for i, m in enumerate(metas):
@@ -73,6 +75,90 @@ def load_feature_container(path: str) -> List[Dict]:
         rd['base_map_info'] = make_base_map_info(z['r%d_refbase' % i], z['r%d_readbase' % i], z['r%d_refbasei' % i],
                                                  z['r%d_readbasei' % i])
         rd['events'] = events_from_bases(z['r%d_evbase' % i])
+        reads.append(rd)
+    return reads
+
+
+# ---------------------------------------------------------------------------------------------
+# packed feature containers (format 2): the same per-read arguments of mPredict1, concatenated over the reads of a
+# container and stored uncompressed, in the dtypes the device consumes - a 30x E. coli run is 1.4e8 table rows, and
+# per-read float64 matrices + U1 columns behind deflate cost 40 % of a worker's host time in round 1.
+#   tx        float32 [R, 7]   mfeatures[:, 3:] of every read, 100 zero-padded rows each side (myDetect.py:850-851)
+#   refbase / readbase  S1 [B] base_map_info columns (dtype :752 of the on-disk table), refbasei int64 [B]
+#   evbase    S1 [E]           basecalled base of every event (model_state[2], :824-833)
+#   row_off / bmi_off / ev_off  int64 [n_reads + 1]
+#   meta      JSON: per read readk, chr, strand, mapped_start, start_clip, end_clip; 'contig_len' {chr: length}
+# ---------------------------------------------------------------------------------------------
+def save_packed_container(path: str, reads: List[Dict], contig_len: Dict[str, int] = None) -> None:
+    """reads: classic read dicts (mfeatures, base_map_info, events, ...) or packed ones (tx, refbase, ..., evbase)."""
+    if not path.endswith(CONTAINER_SUFFIX):
+        raise ValueError('feature containers must end with ' + CONTAINER_SUFFIX)
+    tx, refb, readb, refi, evb, metas = [], [], [], [], [], []
+    for rd in reads:
+        if 'tx' in rd:
+            tx.append(np.asarray(rd['tx'], np.float32))
+            refb.append(np.asarray(rd['refbase'], 'S1'))
+            readb.append(np.asarray(rd['readbase'], 'S1'))
+            refi.append(np.asarray(rd['refbasei'], np.int64))
+            evb.append(np.asarray(rd['evbase'], 'S1'))
+        else:
+            bmi = rd['base_map_info']
+            tx.append(np.asarray(rd['mfeatures'][:, 3:], np.float32))
+            refb.append(bmi['refbase'].astype('S1'))
+            readb.append(bmi['readbase'].astype('S1'))
+            refi.append(bmi['refbasei'].astype(np.int64))
+            evb.append(np.array([s[2] for s in rd['events']['model_state']], dtype='S1'))
+        metas.append({k: rd[k] for k in ('readk', 'chr', 'strand', 'mapped_start', 'start_clip', 'end_clip')})
+    off = lambda parts: np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    cat = lambda parts, dt, shape: np.concatenate(parts) if parts else np.zeros(shape, dt)
+    arrays = {'format': np.array(2), 'tx': cat(tx, np.float32, (0, 7)), 'refbase': cat(refb, 'S1', 0), 'readbase': cat(readb, 'S1', 0),
+              'refbasei': cat(refi, np.int64, 0), 'evbase': cat(evb, 'S1', 0), 'row_off': off(tx), 'bmi_off': off(refb),
+              'ev_off': off(evb), 'meta': np.array(json.dumps({'reads': metas, 'contig_len': contig_len or {}}))}
+    with open(path, 'wb') as fh:
+        np.savez(fh, **arrays)
+
+
+def load_packed(path: str) -> Dict:
+    """-> {'tx', 'refbase', 'readbase', 'refbasei', 'evbase', 'row_off', 'bmi_off', 'ev_off', 'reads' (meta dicts),
+    'contig_len'} for either container format (format-1 files are converted on the fly)."""
+    z = np.load(path, allow_pickle=False)
+    if 'format' in z.files and int(z['format']) == 2:
+        meta = json.loads(str(z['meta']))
+        out = {k: z[k] for k in ('tx', 'refbase', 'readbase', 'refbasei', 'evbase', 'row_off', 'bmi_off', 'ev_off')}
+        out['reads'] = meta['reads']
+        out['contig_len'] = meta.get('contig_len', {})
+        return out
+    metas = json.loads(str(z['meta']))
+    tx = [z['r%d_mfeatures' % i][:, 3:].astype(np.float32) for i in range(len(metas))]
+    refb = [z['r%d_refbase' % i].astype('S1') for i in range(len(metas))]
+    readb = [z['r%d_readbase' % i].astype('S1') for i in range(len(metas))]
+    refi = [z['r%d_refbasei' % i].astype(np.int64) for i in range(len(metas))]
+    evb = [z['r%d_evbase' % i].astype('S1') for i in range(len(metas))]
+    off = lambda parts: np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    cat = lambda parts, dt, shape: np.concatenate(parts) if parts else np.zeros(shape, dt)
+    return {'tx': cat(tx, np.float32, (0, 7)), 'refbase': cat(refb, 'S1', 0), 'readbase': cat(readb, 'S1', 0),
+            'refbasei': cat(refi, np.int64, 0), 'evbase': cat(evb, 'S1', 0), 'row_off': off(tx), 'bmi_off': off(refb),
+            'ev_off': off(evb), 'reads': metas, 'contig_len': {}}
+
+
+def _classic_reads(pk: Dict) -> List[Dict]:
+    """Packed arrays -> the classic per-read dicts (mfeatures float64 [N+200, 10] with the feature columns filled,
+    base_map_info with the reference's dtype, event table carrying the basecalled bases)."""
+    reads = []
+    ro, bo, eo = pk['row_off'], pk['bmi_off'], pk['ev_off']
+    for i, m in enumerate(pk['reads']):
+        rd = dict(m)
+        tx = pk['tx'][ro[i]:ro[i + 1]]
+        mf = np.zeros((len(tx), 10))
+        mf[:, 3:] = tx
+        rd['mfeatures'] = mf
+        sl = slice(bo[i], bo[i + 1])
+        refi = pk['refbasei'][sl].astype(np.uint64)
+        readb = pk['readbase'][sl].astype('U1')
+        ng = readb != '-'
+        rd['base_map_info'] = make_base_map_info(pk['refbase'][sl].astype('U1'), readb, refi,
+                                                 (np.cumsum(ng) - ng).astype(np.uint64))
+        rd['events'] = events_from_bases(pk['evbase'][eo[i]:eo[i + 1]].astype('U1'))
         reads.append(rd)
     return reads
 

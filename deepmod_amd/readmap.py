@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _lib, features, predstore
 
-OUTPUT_WARNING = 1   # myCom.OUTPUT_WARNING
+OUTPUT_WARNING = 2   # myCom.py:7 (OUTPUT_DEBUG 0, OUTPUT_INFO 1, OUTPUT_WARNING 2, OUTPUT_ERROR 3)
 
 
 def handle_line(moptions, sp_param, f5align):

@@ -3,12 +3,12 @@
 Counterpart of the accumulation loop and writer of the reference's sum_handler
 (bin/DeepMod_scripts/myDetect.py:1089-1120): dense int32 counters per contig x strand
 (`touch`, `cov`, `mod`) updated with integer atomics, so the result is independent of read order
-and of how reads were sharded over GPUs; the cross-GPU merge is one integer all-reduce (the
-additive merge the reference does across processes with DeepMod_tools/sum_chr_mod.py:47-52).
+and of how reads were sharded over GPUs; the cross-GPU merge is one integer RCCL reduce over a persistent
+communicator (deepmod_amd/comm.py; the additive merge the reference does across runs with
+DeepMod_tools/sum_chr_mod.py:47-52).
 """
 from __future__ import annotations
 
-import ctypes
 from typing import Optional, Tuple
 
 import numpy as np
@@ -63,6 +63,13 @@ class PositionSummary:
             cls = np.ascontiguousarray(cls, dtype=np.uint8)
         _lib.check(self._lib.dm_summary_add_classified(self._h, _ptr(pos), _ptr(flags), _ptr(cls), n))
 
+    def add_device(self, pos_ptr: int, flags_ptr: int, n: int):
+        """dm_summary_add on raw device addresses."""
+        _lib.check(self._lib.dm_summary_add(self._h, pos_ptr, flags_ptr, n))
+
+    def add_classified_device(self, pos_ptr: int, flags_ptr: int, cls_ptr: int, n: int):
+        _lib.check(self._lib.dm_summary_add_classified(self._h, pos_ptr, flags_ptr, cls_ptr, n))
+
     def sync(self):
         _lib.check(self._lib.dm_summary_sync(self._h))
 
@@ -73,34 +80,16 @@ class PositionSummary:
         _lib.check(self._lib.dm_summary_fetch(self._h, touch.ctypes.data, cov.ctypes.data, mod.ctypes.data))
         return touch, cov, mod
 
-    # -- multi-GPU merges ------------------------------------------------------------------
-    def all_reduce_rccl(self, unique_id: bytes, rank: int, nranks: int):
-        """Native path: RCCL all-reduce(sum, int32) on the counters, communicator built from a
-        128-byte unique id that rank 0 obtained from `rccl_unique_id()` and shared out of band."""
-        buf = ctypes.create_string_buffer(unique_id, 128)
-        _lib.check(self._lib.dm_summary_reduce_rccl(self._h, buf, rank, nranks))
+    def grow(self, new_length: int):
+        """Extend the counters to new_length positions (kept counts, zeros beyond); no-op if not larger."""
+        _lib.check(self._lib.dm_summary_grow(self._h, int(new_length)))
+        self.length = max(self.length, int(new_length))
 
-    def all_reduce_torch(self, dist):
-        """Same merge through an already initialised torch.distributed process group (backend nccl
-        == RCCL): the counters are aliased as a torch tensor via __cuda_array_interface__."""
-        import torch
-        ptr = self._lib.dm_summary_device_ptr(self._h)
-
-        class _Alias:
-            __cuda_array_interface__ = {"shape": (3 * self.length,), "typestr": "<i4", "data": (int(ptr), False),
-                                        "version": 2, "strides": None}
-        self.sync()
-        t = torch.as_tensor(_Alias(), device=torch.device("cuda", self.device))
-        if t.data_ptr() != int(ptr):
-            raise _lib.DeepModHipError("torch did not alias the summary buffer")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize()
-
-
-def rccl_unique_id() -> bytes:
-    buf = ctypes.create_string_buffer(128)
-    _lib.check(_lib.load().dm_rccl_unique_id(buf))
-    return buf.raw
+    # -- multi-GPU merge --------------------------------------------------------------------
+    def reduce(self, comm, root: int = 0):
+        """In-place int32 sum of touch|cov|mod over the ranks of `comm` (deepmod_amd.comm.Communicator): one RCCL
+        reduce to `root` (result valid there), or an all-reduce with root < 0.  Collective: every rank calls it."""
+        _lib.check(self._lib.dm_summary_reduce(self._h, comm._h, root))
 
 
 def bed_lines(chrom: str, strand: str, base: str, touch: np.ndarray, cov: np.ndarray, mod: np.ndarray) -> bytes:

@@ -178,3 +178,98 @@ def write_synthetic_raw_run(out_dir: str, n_reads: int = 40, reads_per_file: int
             files.append(stem + rawreads.RAW_SUFFIX)
             batch = []
     return files, fasta
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size synthetic runs (BASELINE config 3: 4.64 Mb genome at 30x = ~1.4e8 base-positions): vectorised per read,
+# written straight into packed feature containers (deepmod_amd/predstore.py, format 2)
+# ---------------------------------------------------------------------------------------------
+_ACGT = np.frombuffer(b'ACGT', np.uint8)
+_COMP_LUT = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b'ACGT', b'TGCA'):
+    _COMP_LUT[_a] = _b
+_MU_LUT = np.zeros(256, np.float64)
+for _b, _v in _MU.items():
+    _MU_LUT[ord(_b)] = _v
+_CODE_LUT = np.full(256, 4, np.int64)           # A, C, G, T -> 0..3, anything else 4
+for _i, _b in enumerate(b'ACGT'):
+    _CODE_LUT[_b] = _i
+
+
+def synthetic_genome_codes(length: int, seed: int = 1) -> np.ndarray:
+    """uint8 ASCII codes of a uniform ACGT genome."""
+    return _ACGT[np.random.default_rng(seed).integers(0, 4, length)]
+
+
+def synthetic_packed_read(rng, genome: np.ndarray, chrom: str, readk: str, min_len=2000, max_len=10000, p_sub=0.06,
+                          p_ins=0.02, p_del=0.02, max_clip=20, keep_events=False) -> Dict:
+    """One aligned read in the packed layout (tx rows, table columns, event bases): truth alignment with substitutions,
+    single-base insertions and deletions away from the read ends, soft clips, either strand; one event per read base
+    (SURVEY.md 8d generators).  The feature rows are what features.get_Feature builds for this read (tested)."""
+    strand = '+' if rng.random() < 0.5 else '-'
+    span = int(rng.integers(min_len, max_len + 1))
+    start = int(rng.integers(0, len(genome) - span - 1))
+    idx = np.arange(span)
+    interior = (idx > 0) & (idx < span - 1)
+    ins = (interior & (rng.random(span) < p_ins)).astype(np.int64)          # an inserted read base before this position
+    dele = interior & (rng.random(span) < p_del)
+    sub = interior & ~dele & (rng.random(span) < p_sub)
+    g = genome[start:start + span]
+    readb_pos = np.where(sub, _ACGT[(_CODE_LUT[g] + rng.integers(1, 4, span)) % 4], g)
+    readb_pos = np.where(dele, np.uint8(ord('-')), readb_pos)
+    first_row = np.cumsum(1 + ins) - (1 + ins)
+    nrow = int(span + ins.sum())
+    refb = np.full(nrow, ord('-'), np.uint8)
+    readb = np.empty(nrow, np.uint8)
+    refi = np.repeat(start + idx, 1 + ins).astype(np.int64)
+    pos_rows = first_row + ins
+    refb[pos_rows] = g
+    readb[pos_rows] = readb_pos
+    ins_rows = first_row[ins == 1]
+    readb[ins_rows] = _ACGT[rng.integers(0, 4, len(ins_rows))]
+    if strand == '-':        # handle_record flips the table and complements both bases (myDetect.py:661-666)
+        refb, readb, refi = _COMP_LUT[refb[::-1]], _COMP_LUT[readb[::-1]], refi[::-1].copy()
+    aligned = np.flatnonzero(readb != ord('-'))
+    n = len(aligned)
+    start_clip, end_clip = int(rng.integers(0, max_clip + 1)), int(rng.integers(0, max_clip + 1))
+    bases = np.concatenate([_ACGT[rng.integers(0, 4, start_clip)], readb[aligned], _ACGT[rng.integers(0, 4, end_clip)]])
+    nev = len(bases)
+    mean = np.round(np.clip(rng.normal(_MU_LUT[bases], 0.3), -5, 5), 3).astype(np.float32)
+    stdv = np.round(np.abs(rng.normal(0.25, 0.15, nev)), 3).astype(np.float32)
+    length = rng.geometric(0.12, nev).astype(np.float32)
+    tx = np.zeros((n + 200, 7), np.float32)
+    code = _CODE_LUT[refb[aligned]]
+    hit = np.flatnonzero(code < 4)
+    tx[100 + hit, code[hit]] = 1.0
+    ie = np.arange(start_clip - 100, nev - end_clip + 100)
+    ok = (ie >= 0) & (ie < nev)
+    tx[ok, 4] = mean[ie[ok]]
+    tx[ok, 5] = stdv[ie[ok]]
+    tx[ok, 6] = length[ie[ok]]
+    rd = {'readk': readk, 'chr': chrom, 'strand': strand, 'mapped_start': int(refi.min()), 'start_clip': start_clip,
+          'end_clip': end_clip, 'tx': tx, 'refbase': refb.view('S1'), 'readbase': readb.view('S1'), 'refbasei': refi,
+          'evbase': bases.view('S1')}
+    if keep_events:
+        rd['_events'] = (mean, stdv, length)
+    return rd
+
+
+def write_synthetic_packed_run(out_dir: str, genome_len: int = 4_641_652, coverage: float = 30.0, reads_per_file: int = 100,
+                               seed: int = 1, chrom: str = 'NC_000913.3', first_file: int = 0, n_files: int = None,
+                               **read_kw) -> List[str]:
+    """Packed feature containers covering `genome_len` at `coverage` (read lengths U[min_len, max_len]).  Containers are
+    independent of each other (container i is seeded with seed + i), so a subset [first_file, first_file + n_files) can be
+    regenerated alone - the oracle comparison of the full-size test uses the first few."""
+    os.makedirs(out_dir, exist_ok=True)
+    genome = synthetic_genome_codes(genome_len, seed)
+    mean_len = 0.5 * (read_kw.get('min_len', 2000) + read_kw.get('max_len', 10000))
+    total_files = max(1, int(np.ceil(coverage * genome_len / mean_len / reads_per_file)))
+    last = total_files if n_files is None else min(total_files, first_file + n_files)
+    files = []
+    for fi in range(first_file, last):
+        rng = np.random.default_rng([seed, fi])
+        reads = [synthetic_packed_read(rng, genome, chrom, 'read_%05d_%03d' % (fi, j), **read_kw) for j in range(reads_per_file)]
+        path = os.path.join(out_dir, 'reads_%05d%s' % (fi, predstore.CONTAINER_SUFFIX))
+        predstore.save_packed_container(path, reads, {chrom: genome_len})
+        files.append(path)
+    return files

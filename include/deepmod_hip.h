@@ -21,8 +21,9 @@
  *        + the sess.run above, fused on device
  *   dm_summary_create / _add / _add_read / _fetch / _destroy
  *        sum_handler's per-base accumulation    bin/DeepMod_scripts/myDetect.py:1089-1100
- *   dm_summary_reduce_rccl
+ *   dm_comm_create / dm_summary_reduce / dm_comm_destroy
  *        cross-process additive merge           DeepMod_tools/sum_chr_mod.py:47-52
+ *        (the reference merges BED files of separate runs; here: one RCCL reduce per contig x strand)
  *   dm_cluster_create / _predict / _destroy
  *        cluster MLP sess.run([output])         DeepMod_tools/hm_cluster_predict.py:94-103, :158-164
  */
@@ -42,6 +43,7 @@ extern "C" {
 #define DM_ENOMEM (-3)   /* allocation failed */
 #define DM_ESTATE (-4)   /* handle in wrong state */
 #define DM_ERCCL (-5)    /* RCCL could not be loaded or failed */
+#define DM_ERANGE (-6)   /* DM_PREC_F16X3 met an input it cannot represent; the call's results are invalid, repeat with DM_PREC_F32 */
 
 /* model geometry fixed by the shipped checkpoints */
 #define DM_NFEAT 7
@@ -57,7 +59,21 @@ extern "C" {
                               wait with dm_model_sync.  Default 0: every call is synchronous on return. */
 #define DM_PREC_F32 0      /* fp32 MFMA (v_mfma_f32_16x16x4_f32): fp32 products, the TF graph's own arithmetic */
 #define DM_PREC_F16X3 1    /* split-f16 MFMA: every fp32 operand = hi + lo f16, 3 products per fp32 product, fp32
-                              accumulation; max |dp| vs the oracle 1e-6 .. 2e-6 (tolerance of the path: 1e-4), ~3x faster */
+                              accumulation; max |dp| vs the oracle 1e-6 .. 2e-6 (tolerance of the path: 1e-4), ~3x faster.
+                              Range contract (nothing is clamped silently):
+                                * weights: every kernel / bias value times its exponent scale (<= 2.886) must be a finite f16
+                                  (|w| <~ 22,700).  A model that violates this is created with DM_PREC_F32 as its default and
+                                  dm_model_set_option(DM_OPT_PRECISION, DM_PREC_F16X3) returns DM_EINVAL.
+                                * inputs: features 0..5 |x| <= 65504; feature 6 (event length, a raw sample count: reference
+                                  myDetect.py:894-900) |x| <= 65504 * 2^k, k = DM_INFO_F16_LENGTH_SHIFT (10 for ordinary weights):
+                                  beyond 65504 it is fed as x * 2^-k against a weight row stored x 2^k (exact rescale).
+                                  An input outside these bounds (or NaN) makes the call fail with DM_ERANGE - synchronous
+                                  calls on return, DM_OPT_ASYNC calls at the next dm_model_sync. */
+/* dm_model_get_info keys */
+#define DM_INFO_PRECISION 1          /* DM_PREC_* in effect */
+#define DM_INFO_F16_REPRESENTABLE 2  /* 1 if the weights fit DM_PREC_F16X3 */
+#define DM_INFO_F16_LENGTH_SHIFT 3   /* k above */
+#define DM_INFO_DEVICE 4
 
 typedef struct dm_model dm_model;
 typedef struct dm_summary dm_summary;
@@ -78,6 +94,7 @@ dm_model* dm_model_create(int device, const float* weights, size_t n_floats, int
                           int window, int layers);
 void dm_model_destroy(dm_model* m);
 int dm_model_set_option(dm_model* m, int key, int64_t value);
+int dm_model_get_info(dm_model* m, int key, int64_t* value);
 
 /*
  * Classify n windows.  x: [n][21][7] fp32 C-contiguous, host OR device memory (detected).
@@ -95,7 +112,7 @@ int dm_predict_windows(dm_model* m, const float* x, int64_t n, float* prob, uint
 int dm_predict_read(dm_model* m, const float* rows, int64_t m_rows, int64_t first, int64_t count,
                     float* prob, uint8_t* cls);
 
-/* block until all work queued on the model's stream has finished */
+/* block until all work queued on the model's stream has finished; reports a pending DM_ERANGE of asynchronous launches */
 int dm_model_sync(dm_model* m);
 
 /* profiling (DM_OPT_PROFILE=1): summed HIP-event time and launch count of the BiLSTM kernel since
@@ -108,6 +125,9 @@ void* dm_device_alloc(int device, size_t bytes);
 int dm_device_free(int device, void* p);
 int dm_memcpy_h2d(int device, void* dst, const void* src, size_t bytes);
 int dm_memcpy_d2h(int device, void* dst, const void* src, size_t bytes);
+/* host -> device copy queued on the model's stream (ordered with its launches; with DM_OPT_ASYNC a worker refills its
+ * staging buffers without waiting for the device).  src must stay valid until the next dm_model_sync. */
+int dm_model_h2d_async(dm_model* m, void* dst, const void* src, size_t bytes);
 
 /* ------------------------------------------------------------------ per-position summary -- */
 /*
@@ -128,10 +148,31 @@ int dm_summary_add_classified(dm_summary* s, const int64_t* pos, const uint8_t* 
                               int64_t n);
 int dm_summary_sync(dm_summary* s);
 
-/* sum this summary across all ranks of an RCCL communicator created from `unique_id`
- * (128 bytes from dm_rccl_unique_id on rank 0), result valid on every rank. */
+/* grow the counters to new_length positions (existing counts kept, new positions zero); no-op if not larger */
+int dm_summary_grow(dm_summary* s, int64_t new_length);
+
+/* ---- multi-GPU: one process per GPU, a persistent RCCL communicator, one integer reduce per contig x strand -----
+ * Reads shard across processes with no data-path collective; the only exchange is the additive merge of the
+ * per-position counters at the end (what the reference does across runs with DeepMod_tools/sum_chr_mod.py:47-52).
+ *   dm_rccl_unique_id   rank 0 obtains 128 bytes and hands them to the other ranks out of band (deepmod_amd/comm.py:
+ *                       a file in the run's output folder; any byte channel works)
+ *   dm_comm_create      collective: every rank calls it once with the same id; the communicator lives until
+ *                       dm_comm_destroy and serves any number of reduces
+ *   dm_summary_reduce   in-place int32 sum of touch|cov|mod over all ranks.  root >= 0: ncclReduce, result valid on
+ *                       `root` only; root < 0: ncclAllReduce.  All ranks call it with summaries of equal length, in
+ *                       the same order.  Integer sums are order independent: the BED is the same for any GPU count.
+ *   dm_comm_max_f64 / dm_comm_barrier   small host-synchronous helpers (timing max over ranks, rendezvous)
+ *   dm_comm_stats       collectives issued and bytes reduced by this rank so far */
+typedef struct dm_comm dm_comm;
 int dm_rccl_unique_id(void* out128);
-int dm_summary_reduce_rccl(dm_summary* s, const void* unique_id128, int rank, int nranks);
+dm_comm* dm_comm_create(int device, const void* unique_id128, int rank, int nranks);
+void dm_comm_destroy(dm_comm* c);
+int dm_comm_rank(const dm_comm* c);
+int dm_comm_size(const dm_comm* c);
+int dm_comm_barrier(dm_comm* c);
+int dm_comm_max_f64(dm_comm* c, double* value);
+int dm_comm_stats(const dm_comm* c, int64_t* collectives, int64_t* bytes);
+int dm_summary_reduce(dm_summary* s, dm_comm* c, int root);
 
 /* copy counters to host arrays of `length` int32 each (any may be NULL) */
 int dm_summary_fetch(dm_summary* s, int32_t* touch, int32_t* cov, int32_t* mod);

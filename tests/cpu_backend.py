@@ -1,0 +1,60 @@
+"""TEST INFRASTRUCTURE: CPU stand-in for deepmod_amd.stream.HipBackend (oracle classifier + numpy counters), so that
+the streaming engine's host logic and its multi-rank merge can be exercised without a GPU.  Never imported by the product."""
+import numpy as np
+
+from oracle import oracle_np
+
+
+class CpuSummary:
+    def __init__(self, length):
+        self.length = int(length)
+        self.counts = np.zeros(3 * self.length, np.int32)        # touch | cov | mod, like dm_summary's device block
+
+    def grow(self, new_length):
+        new_length = int(new_length)
+        if new_length <= self.length:
+            return
+        nc = np.zeros(3 * new_length, np.int32)
+        for k in range(3):
+            nc[k * new_length:k * new_length + self.length] = self.counts[k * self.length:(k + 1) * self.length]
+        self.counts, self.length = nc, new_length
+
+    def add(self, pos, flags):
+        L = self.length
+        oracle_np.summary_add_c(self.counts[:L], self.counts[L:2 * L], self.counts[2 * L:], pos, flags)
+
+    def fetch(self):
+        L = self.length
+        return self.counts[:L].copy(), self.counts[L:2 * L].copy(), self.counts[2 * L:].copy()
+
+    def close(self):
+        pass
+
+
+class OracleBackend:
+    def __init__(self, weights):
+        self.w = weights
+
+    def new_summary(self, length):
+        return CpuSummary(length)
+
+    def submit(self, pb, summaries):
+        if pb.n_rows == 0:
+            return
+        R = pb.n_rows
+        from numpy.lib.stride_tricks import sliding_window_view
+        win = sliding_window_view(pb.rows, (21, 7))[:, 0]                  # window centred on row r + 10
+        cls = np.zeros(R, np.uint8)
+        cls[10:R - 10] = oracle_np.predict_windows_c(self.w, np.ascontiguousarray(win))[1]
+        for (c, s, lo, hi, xlo, xhi) in pb.groups:
+            summ = summaries(c, s, pb.contig_len.get(c, 0))
+            fl = (pb.flags[lo:hi] & 3) | (cls[lo:hi] << 2)
+            summ.add(pb.pos[lo:hi], fl.astype(np.uint8))
+            if xhi > xlo:
+                summ.add(pb.pos[R + xlo:R + xhi], pb.flags[R + xlo:R + xhi])
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass

@@ -26,10 +26,21 @@ def test_detect_cli_matches_oracle_pipeline(tmp_path, gpu_device):
     w = synth.write_synthetic_checkpoint(prefix, seed=9, scale=4.0)   # min|p1-0.5| = 2.2e-4 on this read set
     out = str(tmp_path / 'out')
     cmd = [sys.executable, os.path.join(ROOT, 'bin', 'DeepMod.py'), 'detect', '--wrkBase', str(wrk), '--modfile', prefix,
-           '--outFolder', out, '--FileID', 'run1', '--threads', '2', '--files_per_thread', '2', '--Base', 'C', '--gpus', '1']
+           '--outFolder', out, '--FileID', 'run1', '--threads', '2', '--files_per_thread', '2', '--Base', 'C', '--gpus', '1',
+           '--storePred', '1']
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
     assert os.path.exists(out + '/run1.done')
+    # the default (streaming) mode on the same inputs: same BED bytes, no per-read files
+    cmd_s = cmd[:-2]
+    cmd_s[cmd_s.index('run1')] = 'stream1'
+    res_s = subprocess.run(cmd_s, capture_output=True, text=True, timeout=600)
+    assert res_s.returncode == 0, res_s.stdout[-1500:] + res_s.stderr[-3000:]
+    assert os.path.exists(out + '/stream1.done') and 'Streaming detect: 24 reads' in res_s.stdout
+    assert not glob.glob(out + '/stream1/*/rnn.pred.detail.npz.*') and not glob.glob(out + '/stream1/rnn.pred.ind.*')
+    for strand in '+-':
+        assert open('%s/stream1/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read() == \
+            open('%s/run1/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read()
 
     # oracle pipeline
     classify = lambda x: oracle_np.predict_windows_c(w, np.asarray(x, np.float32))[1]
@@ -88,10 +99,18 @@ def test_detect_cli_on_raw_containers_matches_oracle_pipeline(tmp_path, gpu_devi
     out = str(tmp_path / 'out')
     cmd = [sys.executable, os.path.join(ROOT, 'bin', 'DeepMod.py'), 'detect', '--wrkBase', str(wrk), '--modfile', prefix,
            '--Ref', fasta, '--outFolder', out, '--FileID', 'raw1', '--threads', '2', '--files_per_thread', '2', '--Base', 'C',
-           '--gpus', '1', '--alignStr', 'minimap2']
+           '--gpus', '1', '--alignStr', 'minimap2', '--storePred', '1']
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
     assert os.path.exists(out + '/raw1.done')
+    cmd_s = cmd[:-2]                                       # default = streaming detect, from DAC samples to BED
+    cmd_s[cmd_s.index('raw1')] = 'rawstream1'
+    res_s = subprocess.run(cmd_s, capture_output=True, text=True, timeout=600)
+    assert res_s.returncode == 0, res_s.stdout[-1500:] + res_s.stderr[-3000:]
+    assert 'Streaming detect: 18 reads' in res_s.stdout
+    for strand in '+-':
+        assert open('%s/rawstream1/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read() == \
+            open('%s/raw1/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read()
 
     genome = readmap.read_fasta(fasta)['chrS']
     classify = lambda x: oracle_np.predict_windows_c(w, np.asarray(x, np.float32))[1]

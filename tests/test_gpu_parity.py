@@ -111,6 +111,99 @@ def test_extreme_inputs_saturate_cleanly(models):
     _check(prob, cls, ref_prob, ref_cls)
 
 
+@pytest.mark.parametrize("scale", [4.0, 16.0])
+def test_event_lengths_beyond_the_f16_range_are_exact(models, scale):
+    """`length` is a raw sample count (myDetect.py:894-900): a stalled event can exceed 65,504 samples, the largest f16.
+    The split-f16 kernel feeds such a value as x * 2^-k against a weight row stored x 2^k (exact) - nothing is clamped."""
+    w, m = models(22, scale)
+    x = synth.synthetic_windows(384, seed=9)
+    rng = np.random.default_rng(1)
+    for lo, val in ((0, 65505.0), (64, 1.0e6), (128, 6.0e7), (192, 70000.0)):
+        sel = rng.random((64, 21)) < 0.3                     # some rows of the window, not all
+        x[lo:lo + 64, :, 6] = np.where(sel, np.float32(val), x[lo:lo + 64, :, 6])
+    x[256:320, 10, 6] = 65504.0                               # the last value of the ordinary slot
+    prob, cls = m.predict_windows(x)
+    assert np.isfinite(prob).all()
+    ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
+    _check(prob, cls, ref_prob, ref_cls)
+
+
+def test_unrepresentable_inputs_are_refused_not_clamped(gpu_device):
+    """DM_PREC_F16X3 range contract (include/deepmod_hip.h): features 0-5 beyond +-65504, a length beyond 65504 * 2^k
+    or a NaN fail the call with DM_ERANGE; the fp32 kernel takes the same input; the model object can fall back."""
+    from deepmod_amd import _lib
+    w = synth.synthetic_weights(22, 4.0)
+    m = model.BiLSTMModel(w, device=gpu_device, precision="f16x3")
+    k = m.get_info(_lib.DM_INFO_F16_LENGTH_SHIFT)
+    assert m.get_info(_lib.DM_INFO_F16_REPRESENTABLE) == 1 and 5 <= k <= 10
+    good = synth.synthetic_windows(300, seed=2)
+    for col, val in ((4, 1.0e5), (6, 65504.0 * 2.0 ** k * 1.01), (5, np.nan)):
+        x = good.copy()
+        x[137, 3, col] = val
+        with pytest.raises(_lib.DeepModRangeError):
+            m.predict_windows(x)
+        p_ok, c_ok = m.predict_windows(good)                 # the flag does not stick
+        assert np.isfinite(p_ok).all()
+        if not np.isnan(val):
+            m.set_precision("f32")
+            p32, c32 = m.predict_windows(x)
+            ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
+            _check(p32, c32, ref_prob, ref_cls)
+            m.set_precision("f16x3")
+    # asynchronous launches report at the next sync
+    m.set_option(_lib.DM_OPT_ASYNC, 1)
+    x = good.copy()
+    x[5, 0, 0] = -1.0e6
+    dx = model.DeviceArray.from_host(x, gpu_device)
+    dc = model.DeviceArray((len(x),), np.uint8, gpu_device)
+    m.predict_windows(dx, cls=dc, want_prob=False)
+    with pytest.raises(_lib.DeepModRangeError):
+        m.sync()
+    m.sync()
+    m.close()
+
+
+def test_weights_outside_the_f16_range_select_the_fp32_kernel(gpu_device):
+    from deepmod_amd import _lib
+    w = synth.synthetic_weights(23, 1.0)
+    name = synth.cell_name("fw", 1, "kernel")
+    w[name] = w[name].copy()
+    w[name][17, 230] = 4.0e4                                  # x 1.4427 = 5.8e4 fits; a forget-gate column
+    m = model.BiLSTMModel(w, device=gpu_device)
+    assert m.get_info(_lib.DM_INFO_F16_REPRESENTABLE) == 1
+    m.close()
+    w[name][17, 130] = 4.0e4                                  # j column: x 2.885 = 1.15e5 does not
+    m = model.BiLSTMModel(w, device=gpu_device)
+    assert m.get_info(_lib.DM_INFO_F16_REPRESENTABLE) == 0 and m.get_info(_lib.DM_INFO_PRECISION) == _lib.DM_PREC_F32
+    with pytest.raises(_lib.DeepModHipError):
+        m.set_precision("f16x3")
+    x = synth.synthetic_windows(200, seed=6)
+    prob, cls = m.predict_windows(x)                          # runs on the fp32 kernel
+    ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
+    _check(prob, cls, ref_prob, ref_cls)
+    m.close()
+
+
+def test_exact_tie_is_class_zero(models):
+    """tf.argmax returns the first maximum (myMultiBiRNN.py:61): p0 == p1 -> class 0.  Head columns and biases made
+    identical give exactly equal logits for every window."""
+    w, _ = models(24, 1.0)
+    w = dict(w)
+    w[synth.HEAD_W] = np.repeat(w[synth.HEAD_W][:, :1], 2, axis=1).copy()
+    w[synth.HEAD_B] = np.array([0.25, 0.25], np.float32)
+    from deepmod_amd import _lib
+    _, m0 = models(24, 1.0)
+    m = model.BiLSTMModel(w, device=m0.device)
+    m.set_option(_lib.DM_OPT_PRECISION, m0.get_info(_lib.DM_INFO_PRECISION))
+    x = synth.synthetic_windows(500, seed=12)
+    prob, cls = m.predict_windows(x)
+    assert np.array_equal(prob, np.full((500, 2), 0.5, np.float32))
+    assert not cls.any()
+    ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
+    assert np.array_equal(ref_prob, prob) and not ref_cls.any()
+    m.close()
+
+
 def test_device_resident_and_host_paths_agree(models, gpu_device):
     w, m = models(21, 4.0)
     x = synth.synthetic_windows(70000, seed=77)  # > one 65,536-window staging batch

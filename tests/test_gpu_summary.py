@@ -66,16 +66,42 @@ def test_empty_add_is_noop(gpu_device):
     assert s.fetch()[0].sum() == 0
 
 
-def test_rccl_all_reduce_single_rank(gpu_device):
-    """nranks = 1 exercises dlopen(librccl), communicator setup and the int32 all-reduce call."""
+def test_persistent_communicator_single_rank(gpu_device, tmp_path):
+    """nranks = 1 exercises dlopen(librccl), the file rendezvous of the unique id, ONE communicator serving several
+    reduces (ncclReduce to root 0 and ncclAllReduce), the barrier / max helpers and the statistics."""
+    from deepmod_amd import comm
+    rdv = comm.FileRendezvous(str(tmp_path / 'rdv'), 0, 1)
+    c = comm.Communicator.from_rendezvous(gpu_device, rdv)
+    sums = []
+    for i, length in enumerate((1000, 70000, 1000)):
+        s = summary.PositionSummary(length, gpu_device)
+        pos, flags = _random_bases(5000, length, seed=i)
+        s.add(pos, flags)
+        before = s.fetch()
+        s.reduce(c, 0 if i < 2 else -1)
+        for b, a in zip(before, s.fetch()):
+            assert np.array_equal(a, b)
+        sums.append(s)
+    c.barrier()
+    assert c.max(3.5) == 3.5
+    st = c.stats()
+    assert st["collectives"] == 3 and st["bytes"] == 4 * 3 * (1000 + 70000 + 1000) and st["rccl_nranks"] == 1
+    c.close()
+
+
+def test_summary_grow_keeps_counts(gpu_device):
     s = summary.PositionSummary(1000, gpu_device)
-    pos, flags = _random_bases(5000, 1000, seed=1)
+    pos, flags = _random_bases(20000, 1000, seed=4)
     s.add(pos, flags)
     before = s.fetch()
-    s.all_reduce_rccl(summary.rccl_unique_id(), 0, 1)
-    after = s.fetch()
-    for b, a in zip(before, after):
-        assert np.array_equal(a, b)
+    s.grow(5000)
+    s.add(np.array([4999], np.int64), np.array([7], np.uint8))
+    t, c, m = s.fetch()
+    assert len(t) == 5000 and t[4999] == 1 and c[4999] == 1 and m[4999] == 1
+    for b, a in zip(before, (t, c, m)):
+        assert np.array_equal(a[:1000], b) and a[1000:4999].sum() == 0
+    s.grow(10)        # never shrinks
+    assert s.length == 5000
 
 
 def test_bed_bytes_from_gpu_counts(gpu_device):

@@ -262,7 +262,7 @@ def test_raw_batch_without_alignment_goes_to_error_channel(tmp_path, hip_lib, mo
                                                        chrom='chrS', min_len=200, max_len=300)
     os.remove(files[0][:-len(rawreads.RAW_SUFFIX)] + '.sam')
     f5data = {'r%d' % i: ('ACGT', None, None, files[0], (0, 0)) for i in range(3)}
-    monkeypatch.setattr(rawreads, 'get_Event_Signals', lambda mo, so, fl: f5data)
+    monkeypatch.setattr(rawreads, 'get_Event_Signals', lambda mo, so, fl, normalizer=None: f5data)
     sp_options = defaultdict()
     sp_options.update({'Mod': [], 'Error': defaultdict(list), 'ctfolder': str(tmp_path), 'batchid': 0})
     detect.mDetect1_raw({'alignStr': 'no-such-aligner', 'Ref': fasta}, sp_options, None, files)

@@ -5,10 +5,11 @@
 
 A "step" is one pass of the hot path over one batch of 65,536 synthetic 7-feature x wd21 windows
 that are already resident in HBM: dm_predict_windows (BiLSTM classify) + dm_summary_add (per-position
-coverage / mod-count accumulate).  N > 1 (launched by torch.distributed.run, one rank per GPU):
-windows shard across ranks with no data-path collective (weak scaling: every rank runs its own K
-batches); the only collective is one integer all-reduce of the per-position counters at the end,
-inside the timed region.  Rank 0 prints ONE JSON line.
+coverage / mod-count accumulate).  N > 1 (launched by torch.distributed.run, one rank per GPU; torch is only the
+launcher): windows shard across ranks with no data-path collective (weak scaling: every rank runs its own K
+batches); the only collective is ONE integer RCCL reduce of the per-position counters into rank 0 at the end,
+inside the timed region, through the product's C ABI (dm_comm_create once, dm_summary_reduce) - barriers and the
+max-over-ranks of the elapsed time go through the same communicator.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -43,56 +44,93 @@ SETUP_LAUNCHES = 32           # untimed classifier launches during setup (GPU po
 
 
 def usable_cores():
-    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (a container
-    that reports 256 logical CPUs but is throttled to a few would otherwise oversubscribe OpenMP)."""
+    """(cores this process may actually use, why): affinity mask capped by the cgroup CPU quota - a container that
+    reports 256 logical CPUs but is throttled to 16 CPU-seconds per second would otherwise oversubscribe OpenMP."""
     try:
         n = len(os.sched_getaffinity(0))
     except Exception:
         n = os.cpu_count() or 1
+    why = "sched_getaffinity: %d of %d logical CPUs" % (n, os.cpu_count() or n)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if quota != "max":
-            n = max(1, min(n, int(float(quota) / float(period))))
+            q = max(1, int(float(quota) / float(period)))
+            if q < n:
+                n = q
+                why += "; cgroup cpu.max %s/%s -> %d CPUs" % (quota, period, q)
     except Exception:
         pass
-    return n
+    return n, why
+
+
+def _timed(fn, n_windows, budget_s):
+    """Run fn() (classifies n_windows) repeatedly for ~budget_s -> (windows/s, windows, seconds)."""
+    fn()                                                   # warm up threads / caches
+    t0 = time.perf_counter()
+    fn()
+    one = max(time.perf_counter() - t0, 1e-6)
+    reps = int(max(1, min(256, budget_s / one)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    dt = time.perf_counter() - t0
+    return reps * n_windows / dt, reps * n_windows, dt
 
 
 def cpu_baseline(weights, x_sample_src):
-    """Oracle (C restatement, OpenMP) on the host cores of this box, bounded to ~12 s of CPU work."""
+    """The CPU path next to the GPU figure: oracle/deepmod_oracle.c - a plain-C fp32 restatement of the
+    TF graph (NOT TensorFlow/Eigen: TF is not installable here), OpenMP over windows - on the host cores of this box,
+    bounded to ~25 s: all usable cores at the GPU batch size (`value`), the same cores fed the reference's own
+    rnn_pred_batch_size = 512 windows per call (myDetect.py:30, :808-812), and one thread."""
     from oracle import oracle_np
-    cores = usable_cores()
+    cores, why = usable_cores()
     oracle_np.build_c_oracle()
-    probe = x_sample_src[:max(256, 32 * cores)]
-    oracle_np.predict_windows_c(weights, probe, nthreads=cores)          # warm up threads / caches
-    t0 = time.perf_counter()
-    oracle_np.predict_windows_c(weights, probe, nthreads=cores)
-    rate = len(probe) / max(time.perf_counter() - t0, 1e-6)
-    reps = int(max(1, min(64, rate * 12.0 / len(x_sample_src))))           # whole passes over batch 0
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        oracle_np.predict_windows_c(weights, x_sample_src, nthreads=cores)
-    dt = time.perf_counter() - t0
-    n = reps * len(x_sample_src)
-    return {"value": n / dt, "unit": "base-positions/s", "cores": cores, "logical_cpus": os.cpu_count(), "kind": "port",
-            "sample": "%d pass(es) over the %d windows of batch 0 (%d windows), oracle/deepmod_oracle.c = fp32 C "
-                      "restatement of the TF graph with libm expf/tanhf (NOT TensorFlow/Eigen), %d OpenMP threads, %.1f s"
-                      % (reps, len(x_sample_src), n, cores, dt)}
+    run = lambda x, t: (lambda: oracle_np.predict_windows_c(weights, x, nthreads=t))
+    sample = x_sample_src[:16384]
+    big, n_big, dt_big = _timed(run(sample, cores), len(sample), 12.0)
+    chunks = [sample[i:i + 512] for i in range(0, 4096, 512)]
+    b512, n512, dt512 = _timed(lambda: [oracle_np.predict_windows_c(weights, c, nthreads=cores) for c in chunks], 4096, 6.0)
+    one, n_one, dt_one = _timed(run(sample[:1024], 1), 1024, 6.0)
+    return {"value": big, "unit": "base-positions/s", "cores": cores, "cores_why": why, "logical_cpus": os.cpu_count(), "kind": "port",
+            "sample": "%d windows (passes over the first 16,384 windows of batch 0) in %.1f s, oracle/deepmod_oracle.c = fp32 C "
+                      "restatement of the TF graph with libm expf/tanhf (scalar-ish loop nest, ~0.4 TFLOP/s; NOT TensorFlow/Eigen), "
+                      "%d OpenMP threads" % (n_big, dt_big, cores),
+            "batch512": {"value": b512, "cores": cores, "sample": "%d windows as calls of 512 (rnn_pred_batch_size, myDetect.py:30) in %.1f s" % (n512, dt512)},
+            "single_thread": {"value": one, "cores": 1, "sample": "%d windows in %.1f s" % (n_one, dt_one)}}
+
+
+def kernel_source_sha():
+    """Hash of the classifier kernel sources: a PMC summary is only valid for the sources it was collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "deepmod_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".inc")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(precision):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/<round>/<precision>/pmc_summary.json: FETCH_SIZE and WRITE_SIZE in KB, separate --pmc
-    passes; gfx950 correction: FETCH_SIZE x 2 for wide coalesced reads, MI355X_MICROARCH.md HBM section)."""
-    path = os.path.join(ROOT, "profiles", "r01", precision, "pmc_summary.json")
-    try:
-        pmc = json.load(open(path))
-        fetch = pmc["FETCH_SIZE"]["mean_per_launch"] * 1024.0
-        write = pmc["WRITE_SIZE"]["mean_per_launch"] * 1024.0
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/<round>/<precision>/pmc_summary.json of the newest round that has one: FETCH_SIZE and WRITE_SIZE in KB,
+    separate --pmc passes; gfx950 correction: FETCH_SIZE x 2 for wide coalesced reads, MI355X_MICROARCH.md HBM section).
+    `stale` is true when the kernel sources changed since that profile was taken."""
+    rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r") and d[1:].isdigit())
+    for rnd in reversed(rounds):
+        path = os.path.join(ROOT, "profiles", rnd, precision, "pmc_summary.json")
+        if not os.path.exists(path):
+            continue
+        try:
+            pmc = json.load(open(path))
+            fetch = pmc["FETCH_SIZE"]["mean_per_launch"] * 1024.0
+            write = pmc["WRITE_SIZE"]["mean_per_launch"] * 1024.0
+        except Exception:
+            continue
         return {"bytes": 2.0 * fetch + write, "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
-                "source": os.path.relpath(path, ROOT), "windows_per_launch": pmc.get("windows_per_launch", BATCH)}
-    except Exception:
-        return None
+                "source": os.path.relpath(path, ROOT), "windows_per_launch": pmc.get("windows_per_launch", BATCH),
+                "profiled_kernel_src_sha": pmc.get("kernel_src_sha"), "kernel_src_sha": kernel_source_sha(),
+                "stale": pmc.get("kernel_src_sha") != kernel_source_sha()}
+    return None
 
 
 def extras(m, _lib, model, precision, x_dev0, x_host0, prob_dev, cls_dev, reps=4):
@@ -143,23 +181,27 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
-    dist = None
     torch = None
     dist_mode = world > 1 or os.environ.get("DM_BENCH_FORCE_DIST") == "1"   # 1-rank dry run of the N > 1 path
     if dist_mode:
-        import torch  # torch first: its HIP/RCCL runtime is the one the process group uses
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        import torch  # loaded first so that ONE HIP / RCCL runtime serves the process (the library dlopens librccl by soname); used for cuda.synchronize only
 
-    from deepmod_amd import _lib, model, summary, synth
+    from deepmod_amd import _lib, comm as dmcomm, model, summary, synth
 
     lib = _lib.load()
     if lib.dm_device_count() < 1:
         raise SystemExit("bench.py: no gfx950 device visible; there is no CPU fallback")
     device = local_rank if dist_mode else 0
 
-    weights = synth.synthetic_weights(seed=7, scale=1.0)
+    communicator = rdv = None
+    if dist_mode:
+        # torch.distributed.run is only the launcher: ranks find each other through a file rendezvous keyed by the
+        # launcher's pid (the common parent of all ranks) and the master port, and talk RCCL through the product's C ABI
+        rdv = dmcomm.FileRendezvous(os.path.join("/tmp", "deepmod_bench_rdv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))),
+                                    rank, world, timeout=300.0, fresh_after=time.time() - 600.0)
+        communicator = dmcomm.Communicator.from_rendezvous(device, rdv)
+
+    weights = synth.synthetic_weights(seed=26, scale=4.0)     # ~50 % of the windows are class 1: both summary branches are taken
     m = model.BiLSTMModel(weights, device=device, precision=args.precision)
     m.set_option(_lib.DM_OPT_PROFILE, 1)
     P = PRECISIONS[args.precision]
@@ -199,13 +241,13 @@ def main():
         if torch is not None:
             torch.cuda.synchronize()
 
-    if torch is None:
-        try:  # contract: bracket the timed region with torch.cuda.synchronize() as well
-            import torch as _t
-            if _t.cuda.is_available():
-                torch = _t
-        except Exception:
-            torch = None
+    try:  # contract: bracket the timed region with torch.cuda.synchronize() as well (torch does nothing else here)
+        import torch as _t
+        if _t.cuda.is_available():
+            _t.cuda.set_device(device)
+            torch = _t
+    except Exception:
+        torch = None
 
     # setup, untimed like the data upload above: bring the GPU out of its idle power state (the first ~10 launches of a
     # process run ~15 % slower than the steady state, profiles/r01/README.md) so that a short --steps run measures the
@@ -217,22 +259,23 @@ def main():
         step(i)
     sync_all()
     m.profile_reset()
-    if dist is not None:
-        dist.barrier()
+    if communicator is not None:
+        communicator.barrier()
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-    if dist_mode:
-        summ.all_reduce_torch(dist)
+    if communicator is not None:
+        summ.reduce(communicator, 0)          # the only collective: int32 touch|cov|mod summed into rank 0 (ncclReduce)
     sync_all()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if communicator is not None:
+        communicator.barrier()
+    elapsed_rank = time.perf_counter() - t0
+    elapsed = communicator.max(elapsed_rank) if communicator is not None else elapsed_rank
+    per_rank = None
+    if communicator is not None:
+        per_rank = rdv.all_gather_json("rate", {"rank": rank, "windows_per_s": BATCH * args.steps / elapsed_rank,
+                                                "elapsed_s": elapsed_rank, "device": device})
 
     kernel_ms, launches, kwindows = m.profile_get()
     total_windows = BATCH * args.steps * world
@@ -260,17 +303,21 @@ def main():
                          "launches": launches, "flop_per_window": FLOP_PER_WINDOW,
                          "peak_note": P["peak_note"],
                          "matrix_pipe_busy_est": achieved * P.get("issued_per_algorithmic", 1.0) / P["peak"]},
-            "summary_check": {"touch": int(touch.sum()), "cov": int(cov.sum()), "mod": int(mod.sum())},
+            "summary_check": {"touch": int(touch.sum()), "cov": int(cov.sum()), "mod": int(mod.sum()),
+                              "note": "rank 0's counters after the reduce = sum over all ranks"},
         }
+        if communicator is not None:
+            out["multi_gpu"] = dict(communicator.stats(), collective="ncclReduce(int32 sum, root 0) via dm_summary_reduce on one persistent "
+                                    "dm_comm", reduce_bytes_per_rank=12 * CONTIG_LEN, per_rank=per_rank)
         if world == 1 and not args.no_extras:
             out["extras"] = extras(m, _lib, model, args.precision, x_dev[0], x0, prob_dev, cls_dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(weights, x0)
         print(json.dumps(out), flush=True)
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if communicator is not None:
+        communicator.barrier()
+        communicator.close()
 
 
 if __name__ == "__main__":

@@ -33,8 +33,9 @@ class FileRendezvous:
     """Byte / JSON exchange between the ranks of one run through files in a directory every rank can see (the run's
     output folder).  Writes are atomic (tmp + rename); readers poll."""
 
-    def __init__(self, directory: str, rank: int, world: int, timeout: float = 600.0):
+    def __init__(self, directory: str, rank: int, world: int, timeout: float = 600.0, fresh_after: float = 0.0):
         self.dir, self.rank, self.world, self.timeout = directory, rank, world, timeout
+        self.fresh_after = fresh_after        # files last written before this time belong to an earlier run: ignored
         os.makedirs(directory, exist_ok=True)
 
     def _path(self, name: str) -> str:
@@ -49,7 +50,7 @@ class FileRendezvous:
     def get(self, name: str) -> bytes:
         deadline = time.time() + self.timeout
         path = self._path(name)
-        while not os.path.exists(path):
+        while not (os.path.exists(path) and os.path.getmtime(path) >= self.fresh_after):
             if time.time() > deadline:
                 raise TimeoutError('rendezvous: %s did not appear within %.0f s' % (path, self.timeout))
             time.sleep(0.005)

@@ -1,0 +1,137 @@
+"""GPU (-m gpu): BASELINE.json configs[2] at full size - a 4.64 Mb genome sequenced at 30x (~1.4e8 base-positions,
+23,000 synthetic reads, SURVEY.md 8d generators) through `bin/DeepMod.py detect` on one GPU:
+
+  * streaming detect (device-resident counters) and the stored path (per-read prediction files + summary workers, the
+    reference's file shape) give byte-identical BED files on the whole run;
+  * on a 1 % read subsample the streaming BED equals the oracle pipeline (C classifier + loop-level mPredict1 /
+    sum_handler restatements) byte for byte, away from near-tie windows (|p1 - 0.5| < 1e-4), which are enumerated;
+  * the end-to-end rate and the host stages' share are printed (pytest -s) and written to gpurun_out/.
+"""
+import glob
+import json
+import multiprocessing
+import os
+import re
+import shutil
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from deepmod_amd import predstore, synth, synth_reads
+
+pytestmark = pytest.mark.gpu
+
+GENOME_LEN = 4_641_652
+COVERAGE = float(os.environ.get("DM_CONFIG3_COVERAGE", "30"))
+CHROM = 'NC_000913.3'
+READS_PER_FILE = 100
+
+
+def _gen(args):
+    out_dir, first, n = args
+    return synth_reads.write_synthetic_packed_run(out_dir, GENOME_LEN, COVERAGE, READS_PER_FILE, seed=1, chrom=CHROM,
+                                                  first_file=first, n_files=n)
+
+
+def _run_cli(extra, timeout=3000):
+    cmd = [sys.executable, os.path.join(ROOT, 'bin', 'DeepMod.py'), 'detect'] + extra
+    t0 = time.time()
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    return res.stdout, time.time() - t0
+
+
+def _parse_bed(data: bytes):
+    rows = {}
+    for ln in data.decode().splitlines():
+        f = ln.split()
+        rows[int(f[1])] = (int(f[9]), int(f[11]), ln)
+    return rows
+
+
+def test_config3_full_size_streaming_equals_stored_and_oracle(tmp_path, gpu_device):
+    wrk = str(tmp_path / 'reads')
+    total_files = int(np.ceil(COVERAGE * GENOME_LEN / 6000.0 / READS_PER_FILE))
+    ncpu = min(32, len(os.sched_getaffinity(0)))
+    chunk = int(np.ceil(total_files / ncpu))
+    t0 = time.time()
+    with multiprocessing.get_context('spawn').Pool(ncpu) as pool:
+        files = sum(pool.map(_gen, [(wrk, i, chunk) for i in range(0, total_files, chunk)]), [])
+    t_gen = time.time() - t0
+    assert len(files) == total_files
+    prefix = str(tmp_path / 'model' / 'mod_train_synth')
+    os.makedirs(os.path.dirname(prefix))
+    w = synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)
+    out = str(tmp_path / 'out')
+    common = ['--wrkBase', wrk, '--modfile', prefix, '--outFolder', out, '--Base', 'C', '--gpus', '1',
+              '--threads', str(ncpu), '--files_per_thread', '4']
+
+    so, t_stream = _run_cli(common + ['--FileID', 'stream'])
+    m = re.search(r'Streaming detect: (\d+) reads, (\d+) base-positions .* = ([0-9.e+]+) base-positions/s', so)
+    assert m, so[-2000:]
+    n_reads, n_pos, rate = int(m.group(1)), int(m.group(2)), float(m.group(3))
+    assert n_reads == total_files * READS_PER_FILE
+    assert n_pos > 0.95 * COVERAGE * GENOME_LEN
+
+    _, t_stored = _run_cli(common + ['--FileID', 'stored', '--storePred', '1'])
+    sizes = {}
+    for strand in '+-':
+        a = open('%s/stream/mod_pos.%s%s.C.bed' % (out, CHROM, strand), 'rb').read()
+        b = open('%s/stored/mod_pos.%s%s.C.bed' % (out, CHROM, strand), 'rb').read()
+        assert a == b, 'streaming and stored BED differ on strand %s' % strand
+        sizes[strand] = a.count(b'\n')
+        assert sizes[strand] > 0.9 * 0.25 * GENOME_LEN          # nearly every C of the strand is covered at 30x
+
+    # ---- 1 % read subsample against the oracle pipeline
+    from oracle import detect_oracle, oracle_np
+    sub = str(tmp_path / 'sub')
+    os.makedirs(sub)
+    n_sub = max(1, int(round(0.01 * total_files)))
+    for f in files[:n_sub]:
+        shutil.copy(f, sub)
+    _run_cli(['--wrkBase', sub, '--modfile', prefix, '--outFolder', out, '--Base', 'C', '--gpus', '1', '--threads', '4',
+              '--files_per_thread', '2', '--FileID', 'sub'])
+    by, tie_pos = {'+': [], '-': []}, {'+': {}, '-': {}}
+    n_win = n_tie = 0
+    for f in files[:n_sub]:
+        pk = predstore.load_packed(f)
+        ro, bo, eo = pk['row_off'], pk['bmi_off'], pk['ev_off']
+        for i, meta in enumerate(pk['reads']):
+            tx = pk['tx'][ro[i]:ro[i + 1]]
+            n = int(eo[i + 1] - eo[i]) - meta['start_clip'] - meta['end_clip']
+            win = np.lib.stride_tricks.sliding_window_view(tx, (21, 7))[:, 0][90:90 + n]
+            prob, cls = oracle_np.predict_windows_c(w, np.ascontiguousarray(win))
+            readb = pk['readbase'][bo[i]:bo[i + 1]]
+            refi = pk['refbasei'][bo[i]:bo[i + 1]]
+            aligned = np.flatnonzero(readb != b'-')[:n]
+            mod_pred = np.zeros(len(readb), np.int64)
+            mod_pred[aligned[cls == 1]] = 1
+            near = np.abs(prob[:, 1] - 0.5) < 1e-4
+            n_win += n
+            n_tie += int(near.sum())
+            for p in refi[aligned[near]]:
+                tie_pos[meta['strand']][int(p)] = tie_pos[meta['strand']].get(int(p), 0) + 1
+            by[meta['strand']].append({'refbase': pk['refbase'][bo[i]:bo[i + 1]].tobytes().decode(), 'readbase': readb.tobytes().decode(),
+                                       'refbasei': refi.tolist(), 'mod_pred': mod_pred.tolist()})
+    assert n_tie <= 1e-3 * n_win
+    for strand in '+-':
+        want = detect_oracle.sum_handler_oracle(CHROM, strand, 'C', by[strand])
+        got = open('%s/sub/mod_pos.%s%s.C.bed' % (out, CHROM, strand), 'rb').read()
+        if got != want:            # only positions under a near-tie window may differ, by at most that many calls
+            g, o = _parse_bed(got), _parse_bed(want)
+            assert g.keys() == o.keys()
+            for pos in g:
+                if g[pos][2] != o[pos][2]:
+                    assert g[pos][0] == o[pos][0] and abs(g[pos][1] - o[pos][1]) <= tie_pos[strand].get(pos, 0), (pos, g[pos], o[pos])
+    report = {"config": "configs[2] E. coli 4.64 Mb at %gx, 1 GPU" % COVERAGE, "reads": n_reads, "base_positions": n_pos,
+              "streaming_cli_wall_s": t_stream, "streaming_base_positions_per_s": rate, "stored_cli_wall_s": t_stored,
+              "generation_s": t_gen, "bed_lines": sizes, "oracle_subsample": {"files": n_sub, "windows": n_win, "near_ties": n_tie},
+              "streaming_stdout_tail": so.strip().splitlines()[-4:]}
+    print(json.dumps(report, indent=1))
+    dest = os.path.join(ROOT, 'gpurun_out', 'r02')
+    os.makedirs(dest, exist_ok=True)
+    json.dump(report, open(os.path.join(dest, 'config3_fullsize.json'), 'w'), indent=1)

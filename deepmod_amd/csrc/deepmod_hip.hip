@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/deepmod_hip.h"
@@ -20,6 +21,7 @@
 #else
 #include "lstm_f16.hip.inc"
 #endif
+#include "lstm_f16t.hip.inc"
 
 #ifdef DM_TRACE2
 #define DM16_TRACE2_LDS 2048
@@ -209,6 +211,76 @@ Packed16 pack_weights_f16(const float* flat) {
     return P;
 }
 
+// tile-major split-f16 packing (lstm_f16t.hip.inc): [dir][layer][tile][k16-step][hi|lo][lane][8 x f16].
+// A-operand lane l of record (tile T, k16-step t): gate row m = l % 32 -> unit 8T + m / 4, gate m % 4;
+// k = (half = l / 32, j = 0..7) -> K slot of the B operand the kernel builds in registers:
+//   t < 6 : own unit 8 (2t + j/4) + 2 (j%4) + half
+//   t == 6: j < 4: own unit 96 + 2j + half (slot 100 = the constant 1.0 -> bias row; 101..103 zero);
+//           j >= 4: layer 0: feature 2 (j-4) + half (7 = event length x 2^-len_shift); layers 1, 2: input unit 96 + 2 (j-4) + half
+//   t > 6 : input unit 8 (2 (t-7) + j/4) + 2 (j%4) + half
+Packed16 pack_weights_f16t(const float* flat) {
+    using namespace lstm16t;
+    Packed16 P;
+    P.w.assign(WEIGHT_BYTES, 0);
+    P.len_shift = choose_len_shift(flat);
+    const float len_mul = std::ldexp(1.0f, P.len_shift);
+    const float* p = flat;
+    for (int d = 0; d < 2; ++d) {
+        size_t off = size_t(d) * WEIGHT_BYTES_DIR;
+        for (int l = 0; l < 3; ++l) {
+            const int kin = l == 0 ? NFEAT : HID;
+            const int nks = l == 0 ? KS_L0 : KS_L12;
+            const float* kern = p;
+            const float* bias = p + size_t(kin + HID) * 400;
+            p += size_t(kin + HID) * 400 + 400;
+            for (int T = 0; T < NTILE; ++T)
+                for (int t = 0; t < nks; ++t) {
+                    _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + off);
+                    off += REC_BYTES;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int m = lane & 31, half = lane >> 5;
+                        const int unit = 8 * T + m / 4, gate = m % 4;
+                        for (int j = 0; j < 8; ++j) {
+                            float v = 0.0f;
+                            if (unit < HID) {
+                                const int gc = gate * 100 + unit;
+                                int krow = -1;          // row of the TF kernel; -2 = bias row; -1 = zero
+                                float mul = 1.0f;
+                                if (t < 6 || (t == 6 && j < 4)) {                       // own hidden state
+                                    const int u = t < 6 ? 8 * (2 * t + j / 4) + 2 * (j % 4) + half : 96 + 2 * j + half;
+                                    if (u < HID) krow = kin + u;
+                                    else if (u == HID) krow = -2;
+                                } else if (t == 6) {
+                                    const int f = 2 * (j - 4) + half;
+                                    if (l == 0) {
+                                        if (f < NFEAT) krow = f;
+                                        else {
+                                            krow = NFEAT - 1;
+                                            mul = len_mul;
+                                        }
+                                    } else if (96 + f < HID) krow = 96 + f;
+                                } else {
+                                    const int u = 8 * (2 * (t - 7) + j / 4) + 2 * (j % 4) + half;
+                                    if (u < HID) krow = u;
+                                }
+                                if (krow >= 0) v = kern[size_t(krow) * 400 + gc];
+                                else if (krow == -2) v = bias[gc] + (gate == 2 ? 1.0f : 0.0f);   // + forget_bias
+                                v *= gate_scale(gc) * mul;
+                            }
+                            if (!std::isfinite(v)) P.finite = false;
+                            else P.max_abs = std::max(P.max_abs, std::fabs(v));
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)(v - (float)hi);
+                            dst[(0 * 64 + lane) * 8 + j] = hi;
+                            dst[(1 * 64 + lane) * 8 + j] = lo;
+                        }
+                    }
+                }
+        }
+    }
+    return P;
+}
+
 // ---------------------------------------------------------------------------------------------
 // summary kernel: dense int32 counters with a wavefront-level pre-reduction.
 // Bases arrive read by read, so a wave mostly sees 64 consecutive distinct positions (one atomic per
@@ -315,6 +387,7 @@ struct dm_model {
     float* d_bpack = nullptr;
     float* d_hpack = nullptr;
     unsigned char* d_wpack16 = nullptr;   // split-f16 weights (DM_PREC_F16X3)
+    unsigned char* d_wpack16t = nullptr;  // split-f16 weights, tile-major kernel
     float* d_wout = nullptr;              // head W[200][2] fp32 (DM_PREC_F16X3)
     float* d_scratch = nullptr;
     unsigned long long* d_dbg = nullptr;  // DM_TIMING builds only
@@ -415,6 +488,18 @@ int ensure_f16(dm_model* m) {
     return DM_OK;
 }
 
+int ensure_f16t(dm_model* m) {
+    if (m->d_wpack16t) return DM_OK;
+    int rc = ensure_f16(m);          // representability check, head weights, len_shift
+    if (rc) return rc;
+    Packed16 P = pack_weights_f16t(m->host_weights.data());
+    HIP_TRY(hipMalloc(&m->d_wpack16t, P.w.size()));
+    HIP_TRY(hipMemcpy(m->d_wpack16t, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16t::bilstm_f16t_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16t::LDS_BYTES)));
+    return DM_OK;
+}
+
 // launch on device-resident buffers
 int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, float* d_prob, uint8_t* d_cls) {
     if (n <= 0) return DM_OK;
@@ -436,7 +521,31 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         ++m->events_used;
         HIP_TRY(hipEventRecord(e0, m->stream));
     }
-    if (m->precision == DM_PREC_F16X3) {
+    if (m->precision == DM_PREC_F16X3T) {
+        using namespace lstm16t;
+        int rc = ensure_f16t(m);
+        if (rc) return rc;
+        Params p;
+        p.wpack = m->d_wpack16t;
+        p.hpack = m->d_wout;
+        p.bout0 = m->bout[0];
+        p.bout1 = m->bout[1];
+        p.x = d_x;
+        p.xstride = xstride;
+        p.n = n;
+        p.scratch = reinterpret_cast<unsigned char*>(m->d_scratch);
+        p.ntiles = int((n + TILE_M - 1) / TILE_M);
+        int rcp = ensure_plogit(m, p.ntiles);
+        if (rcp) return rcp;
+        p.plogit = m->d_plogit;
+        p.len_scale = std::ldexp(1.0f, -m->len_shift);
+        p.range_flag = m->d_range_flag;
+        const int grid = std::min(2 * p.ntiles, m->grid_cap);
+        hipLaunchKernelGGL(bilstm_f16t_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
+        const long long npad = (long long)p.ntiles * TILE_M;
+        hipLaunchKernelGGL(lstm16::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
+                           npad, m->bout[0], m->bout[1], d_prob, d_cls);
+    } else if (m->precision == DM_PREC_F16X3) {
         using namespace lstm16;
         int rc = ensure_f16(m);
         if (rc) return rc;
@@ -625,7 +734,8 @@ int model_init(dm_model* m, const float* weights) {
     HIP_TRY(hipMemcpy(m->d_wpack, P.w.data(), P.w.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_bpack, P.b.data(), P.b.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_hpack, P.h.data(), P.h.size() * sizeof(float), hipMemcpyHostToDevice));
-    const size_t scratch_bytes = size_t(m->grid_cap) * std::max(SCRATCH_FLOATS_PER_WG * sizeof(float), lstm16::SCRATCH_BYTES_PER_WG);
+    const size_t scratch_bytes = size_t(m->grid_cap) * std::max({SCRATCH_FLOATS_PER_WG * sizeof(float), lstm16::SCRATCH_BYTES_PER_WG,
+                                                                 lstm16t::SCRATCH_BYTES_PER_WG});
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
     HIP_TRY(hipMemset(m->d_scratch, 0, scratch_bytes));
 #if defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2)
@@ -709,6 +819,7 @@ void dm_model_destroy(dm_model* m) {
     (void)hipFree(m->d_hpack);
     (void)hipFree(m->d_scratch);
     (void)hipFree(m->d_wpack16);
+    (void)hipFree(m->d_wpack16t);
     (void)hipFree(m->d_wout);
     (void)hipFree(m->d_dbg);
     (void)hipFree(m->d_plogit);
@@ -732,8 +843,8 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
             m->async = value != 0;
             return DM_OK;
         case DM_OPT_PRECISION:
-            if (value != DM_PREC_F32 && value != DM_PREC_F16X3) return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
-            if (value == DM_PREC_F16X3 && !m->f16_ok)
+            if (value != DM_PREC_F32 && value != DM_PREC_F16X3 && value != DM_PREC_F16X3T) return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
+            if (value != DM_PREC_F32 && !m->f16_ok)
                 return fail(DM_EINVAL, "DM_PREC_F16X3 refused: a packed weight of this model is outside the f16 range (|w| x 2.886 > 65504)");
             m->precision = int(value);
             return DM_OK;

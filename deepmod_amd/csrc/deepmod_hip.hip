@@ -540,6 +540,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         p.plogit = m->d_plogit;
         p.len_scale = std::ldexp(1.0f, -m->len_shift);
         p.range_flag = m->d_range_flag;
+        p.dbg = m->d_dbg;
         const int grid = std::min(2 * p.ntiles, m->grid_cap);
         hipLaunchKernelGGL(bilstm_f16t_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
         const long long npad = (long long)p.ntiles * TILE_M;
@@ -738,7 +739,7 @@ int model_init(dm_model* m, const float* weights) {
                                                                  lstm16t::SCRATCH_BYTES_PER_WG});
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
     HIP_TRY(hipMemset(m->d_scratch, 0, scratch_bytes));
-#if defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2)
+#if defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2) || defined(DM16T_TRACE)
     HIP_TRY(hipMalloc(&m->d_dbg, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(m->d_dbg, 0, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long)));
 #endif

@@ -16,18 +16,18 @@
 
 #include "../../include/deepmod_hip.h"
 #include "lstm_f32.hip.inc"
-#ifdef DM16_NSPLIT      // experimental layout (the two waves of a SIMD share two M-tiles and split the N-tiles; A operands
-#include "lstm_f16_nsplit.hip.inc"   // fetched per k-step): parity-clean, 2.22 ms vs 2.03 ms per launch in round 1 - see profiles/r01
-#else
 #include "lstm_f16.hip.inc"
-#endif
+#ifdef DM_EXPERIMENT_F16T   // tools/experiments/f16t: tile-major split-f16 kernel (parity-clean, same speed: profiles/r02/README.md); dev builds only
 #include "lstm_f16t.hip.inc"
+#endif
 
 #ifdef DM_TRACE2
 #define DM16_TRACE2_LDS 2048
 #else
 #define DM16_TRACE2_LDS 0
 #endif
+
+#define DM_PREC_F16X3T 2   /* DM_EXPERIMENT_F16T builds: the tile-major kernel of tools/experiments/f16t */
 
 namespace {
 
@@ -211,6 +211,7 @@ Packed16 pack_weights_f16(const float* flat) {
     return P;
 }
 
+#ifdef DM_EXPERIMENT_F16T
 // tile-major split-f16 packing (lstm_f16t.hip.inc): [dir][layer][tile][k16-step][hi|lo][lane][8 x f16].
 // A-operand lane l of record (tile T, k16-step t): gate row m = l % 32 -> unit 8T + m / 4, gate m % 4;
 // k = (half = l / 32, j = 0..7) -> K slot of the B operand the kernel builds in registers:
@@ -280,6 +281,8 @@ Packed16 pack_weights_f16t(const float* flat) {
     }
     return P;
 }
+
+#endif  // DM_EXPERIMENT_F16T
 
 // ---------------------------------------------------------------------------------------------
 // summary kernel: dense int32 counters with a wavefront-level pre-reduction.
@@ -387,7 +390,7 @@ struct dm_model {
     float* d_bpack = nullptr;
     float* d_hpack = nullptr;
     unsigned char* d_wpack16 = nullptr;   // split-f16 weights (DM_PREC_F16X3)
-    unsigned char* d_wpack16t = nullptr;  // split-f16 weights, tile-major kernel
+    unsigned char* d_wpack16t = nullptr;  // split-f16 weights of the experimental tile-major kernel (DM_EXPERIMENT_F16T builds)
     float* d_wout = nullptr;              // head W[200][2] fp32 (DM_PREC_F16X3)
     float* d_scratch = nullptr;
     unsigned long long* d_dbg = nullptr;  // DM_TIMING builds only
@@ -488,6 +491,7 @@ int ensure_f16(dm_model* m) {
     return DM_OK;
 }
 
+#ifdef DM_EXPERIMENT_F16T
 int ensure_f16t(dm_model* m) {
     if (m->d_wpack16t) return DM_OK;
     int rc = ensure_f16(m);          // representability check, head weights, len_shift
@@ -499,6 +503,8 @@ int ensure_f16t(dm_model* m) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16t::LDS_BYTES)));
     return DM_OK;
 }
+
+#endif
 
 // launch on device-resident buffers
 int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, float* d_prob, uint8_t* d_cls) {
@@ -521,6 +527,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         ++m->events_used;
         HIP_TRY(hipEventRecord(e0, m->stream));
     }
+#ifdef DM_EXPERIMENT_F16T
     if (m->precision == DM_PREC_F16X3T) {
         using namespace lstm16t;
         int rc = ensure_f16t(m);
@@ -546,7 +553,9 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         const long long npad = (long long)p.ntiles * TILE_M;
         hipLaunchKernelGGL(lstm16::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
                            npad, m->bout[0], m->bout[1], d_prob, d_cls);
-    } else if (m->precision == DM_PREC_F16X3) {
+    } else
+#endif
+    if (m->precision == DM_PREC_F16X3) {
         using namespace lstm16;
         int rc = ensure_f16(m);
         if (rc) return rc;
@@ -564,11 +573,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         p.scratch = reinterpret_cast<unsigned char*>(m->d_scratch);
         p.ntiles = int((n + TILE_M - 1) / TILE_M);
         p.dbg = m->d_dbg;
-#ifdef DM16_NSPLIT
-        p.dir_split = 0;
-#else
         p.dir_split = 1;      // work item = (tile, direction): half the latency of small batches, finer tail on large ones
-#endif
         if (p.dir_split) {
             int rcp = ensure_plogit(m, p.ntiles);
             if (rcp) return rcp;
@@ -735,8 +740,10 @@ int model_init(dm_model* m, const float* weights) {
     HIP_TRY(hipMemcpy(m->d_wpack, P.w.data(), P.w.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_bpack, P.b.data(), P.b.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_hpack, P.h.data(), P.h.size() * sizeof(float), hipMemcpyHostToDevice));
-    const size_t scratch_bytes = size_t(m->grid_cap) * std::max({SCRATCH_FLOATS_PER_WG * sizeof(float), lstm16::SCRATCH_BYTES_PER_WG,
-                                                                 lstm16t::SCRATCH_BYTES_PER_WG});
+    size_t scratch_bytes = size_t(m->grid_cap) * std::max(SCRATCH_FLOATS_PER_WG * sizeof(float), lstm16::SCRATCH_BYTES_PER_WG);
+#ifdef DM_EXPERIMENT_F16T
+    scratch_bytes = std::max(scratch_bytes, size_t(m->grid_cap) * lstm16t::SCRATCH_BYTES_PER_WG);
+#endif
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
     HIP_TRY(hipMemset(m->d_scratch, 0, scratch_bytes));
 #if defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2) || defined(DM16T_TRACE)
@@ -844,7 +851,13 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
             m->async = value != 0;
             return DM_OK;
         case DM_OPT_PRECISION:
-            if (value != DM_PREC_F32 && value != DM_PREC_F16X3 && value != DM_PREC_F16X3T) return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
+#ifdef DM_EXPERIMENT_F16T
+            if (value == DM_PREC_F16X3T && m->f16_ok) {
+                m->precision = int(value);
+                return DM_OK;
+            }
+#endif
+            if (value != DM_PREC_F32 && value != DM_PREC_F16X3) return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
             if (value != DM_PREC_F32 && !m->f16_ok)
                 return fail(DM_EINVAL, "DM_PREC_F16X3 refused: a packed weight of this model is outside the f16 range (|w| x 2.886 > 65504)");
             m->precision = int(value);

@@ -69,7 +69,6 @@ extern "C" {
                                   beyond 65504 it is fed as x * 2^-k against a weight row stored x 2^k (exact rescale).
                                   An input outside these bounds (or NaN) makes the call fail with DM_ERANGE - synchronous
                                   calls on return, DM_OPT_ASYNC calls at the next dm_model_sync. */
-#define DM_PREC_F16X3T 2   /* the same split-f16 arithmetic and range contract, tile-major kernel (csrc/lstm_f16t.hip.inc) */
 /* dm_model_get_info keys */
 #define DM_INFO_PRECISION 1          /* DM_PREC_* in effect */
 #define DM_INFO_F16_REPRESENTABLE 2  /* 1 if the weights fit DM_PREC_F16X3 */

@@ -26,7 +26,7 @@ def _check(prob, cls, ref_prob, ref_cls):
     return err
 
 
-@pytest.fixture(scope="module", params=["f32", "f16x3", "f16x3t"])
+@pytest.fixture(scope="module", params=["f32", "f16x3"])
 def models(gpu_device, request):
     """Every parity test runs for both precision modes of the library: exact-fp32 MFMA and the split-f16
     (3 products per fp32 product) MFMA path.  Same tolerance for both."""

@@ -15,7 +15,6 @@ VARIANTS = {
     "nobar": ["-DDM_ABL_NOBAR"],
     "nodma": ["-DDM_ABL_NODMA"],
     "noldsb": ["-DDM16_ABL_NOLDSB"], "nodma16": ["-DDM16_ABL_NODMA"], "noldsb_nodma": ["-DDM16_ABL_NOLDSB", "-DDM16_ABL_NODMA"],
-    "nsplit": ["-DDM16_NSPLIT"], "nsplit_timing": ["-DDM16_NSPLIT", "-DDM_TIMING"], "nsplit_trace": ["-DDM16_NSPLIT", "-DDM_TRACE"],
     "bdepth1": ["-DDM16_BDEPTH=1"], "bdepth3": ["-DDM16_BDEPTH=3"], "bdepth4": ["-DDM16_BDEPTH=4"],
     "tiles3": ["-DDM_TRACE2=3"], "tiles0": ["-DDM_TRACE2=0"], "tiles6": ["-DDM_TRACE2=6"],
     "nobar16": ["-DDM16_ABL_NOBAR"], "nobar_nodma16": ["-DDM16_ABL_NOBAR", "-DDM16_ABL_NODMA"], "skeleton16": ["-DDM16_ABL_NOBAR", "-DDM16_ABL_NODMA", "-DDM16_ABL_NOLDSB"],

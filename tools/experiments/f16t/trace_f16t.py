@@ -1,15 +1,16 @@
 """Dev tool: per-wave timeline of one stage of the tile-major split-f16 kernel (a -DDM16T_TRACE build).
-    python tools/trace_f16t.py build     # here (cross-compile tools/_abl/lib_f16t_trace.so)
-    python tools/trace_f16t.py run       # on the GPU box
+    python tools/experiments/f16t/trace_f16t.py build     # here (cross-compile tools/_abl/lib_f16t_trace.so)
+    python tools/experiments/f16t/trace_f16t.py run       # on the GPU box
 """
 import ctypes, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(ROOT, "tools", "_abl", "lib_f16t_trace%s.so" % os.environ.get("DM_TAG", ""))
 if sys.argv[1] == "build":
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     src = os.path.join(ROOT, "deepmod_amd", "csrc", "deepmod_hip.hip")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB, src, "-ldl",
-                           "-DDM16T_TRACE=%s" % os.environ.get("DM_TRACE_LAYER", "1")] + sys.argv[2:], cwd=os.path.dirname(src))
+                           "-DDM_EXPERIMENT_F16T", "-I" + HERE, "-DDM16T_TRACE=%s" % os.environ.get("DM_TRACE_LAYER", "1")] + sys.argv[2:], cwd=os.path.dirname(src))
     sys.exit(0)
 sys.path.insert(0, ROOT)
 import numpy as np

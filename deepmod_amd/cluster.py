@@ -6,7 +6,7 @@ For every CpG-motif C with coverage in a DeepMod BED: 14 features
    11-bin histogram of the neighbours' fractions (0.1 bins) normalised by #neighbours]
 over the CpG sites within +-25 bp that are present in the BED (hm_cluster_predict.py:128-154), then the
 MLP 14->100->20->1 on the GPU (dm_cluster_predict) and the original BED line with int(p*100) appended (:170).
-Feature extraction is vectorised numpy on the host (searchsorted instead of dict probes).
+Feature extraction is vectorised numpy on the host (searchsorted and per-bin prefix counts instead of dict probes).
 """
 from __future__ import annotations
 
@@ -118,6 +118,10 @@ def cluster_features(pred) -> Tuple[np.ndarray, List[str]]:
     frac_all = np.concatenate([pred["+"][1], pred["-"][1]])
     order = np.argsort(pos_all, kind="stable")
     spos, sfrac = pos_all[order], frac_all[order]           # a position is a CpG C on at most one strand
+    bins = (sfrac / 0.1 + 0.5).astype(np.int64)             # int(frac/0.1+0.5)  (:144)
+    cum = np.zeros((11, len(spos) + 1), np.int64)
+    for b in range(11):
+        cum[b, 1:] = np.cumsum(bins == b)
     feats, lines = [], []
     for s in "+-":
         pos, frac, ln = pred[s]
@@ -131,17 +135,18 @@ def cluster_features(pred) -> Tuple[np.ndarray, List[str]]:
             j = np.clip(np.searchsorted(opos, ppos), 0, len(opos) - 1)
             hit = opos[j] == ppos
             x[hit, 1] = ofrac[j[hit]]
+        # neighbourhood histogram without a per-site loop: per-bin prefix counts over the position-sorted sites give the
+        # counts of any [pos - 25, pos + 25] range as a difference; the site itself and its partner C are taken out again
         lo = np.searchsorted(spos, pos - NBSIZE, side="left")
         hi = np.searchsorted(spos, pos + NBSIZE, side="right")
-        for i in range(n):
-            nb_pos = spos[lo[i]:hi[i]]
-            nb_frac = sfrac[lo[i]:hi[i]]
-            keep = (nb_pos != pos[i]) & (nb_pos != ppos[i])
-            if keep.any():
-                bins = (nb_frac[keep] / 0.1 + 0.5).astype(np.int64)      # int(frac/0.1+0.5)  (:144)
-                cnt = np.bincount(bins, minlength=11)
-                x[i, 2] = keep.sum()
-                x[i, 3:] = np.round(cnt / float(keep.sum()), 3)
+        cnt = cum[:, hi] - cum[:, lo]                                         # [11, n]
+        for v in (pos, ppos):
+            l, r = np.searchsorted(spos, v, side="left"), np.searchsorted(spos, v, side="right")
+            cnt -= cum[:, r] - cum[:, l]
+        nkeep = cnt.sum(axis=0)
+        has = nkeep > 0
+        x[:, 2] = nkeep
+        x[has, 3:] = np.round(cnt[:, has].T / nkeep[has, None].astype(np.float64), 3)
         feats.append(x)
         lines.extend(ln)
     return np.concatenate(feats) if feats else np.zeros((0, 14)), lines

@@ -87,7 +87,7 @@ def scatter_predictions(modevents, base_map_info, start_clip, n, mfpred_output):
     aligned = np.flatnonzero(base_map_info['readbase'] != '-')[:n]
     if len(aligned) < n:
         raise IndexError('base_map_info has %d aligned read bases but %d events are aligned' % (len(aligned), n))
-    ev_base = np.array([s[2] for s in modevents['model_state'][start_clip:start_clip + n]], dtype='U1')
+    ev_base = rawreads.event_bases(modevents['model_state'][start_clip:start_clip + n])
     bad = np.flatnonzero(base_map_info['readbase'][aligned] != ev_base)
     for b in bad:
         print('Error Does not match', base_map_info['readbase'][aligned[b]], ev_base[b], aligned[b], b + start_clip)

@@ -13,6 +13,14 @@ import numpy as np
 g_ACGT = ['A', 'C', 'G', 'T']   # myCom.py g_ACGT
 
 
+def _event_bases(model_state) -> np.ndarray:
+    """model_state[2] of every event as a 'U1' array (no Python loop over the events)."""
+    ms = np.ascontiguousarray(model_state)
+    if len(ms) == 0:
+        return np.zeros(0, 'U1')
+    return ms.view('U1').reshape(len(ms), ms.dtype.itemsize // 4)[:, 2]
+
+
 def get_Feature(moptions, sp_options, sp_param, f5align, f5data, readk, start_clip, end_clip, base_map_info,
                 forward_reverse, rname, mapped_start_pos, num_insertions, num_deletions):
     if moptions['fnum'] != 7:
@@ -31,7 +39,7 @@ def get_Feature(moptions, sp_options, sp_param, f5align, f5data, readk, start_cl
     refpos = start + step * (np.cumsum(has_ref) - has_ref)
     aligned = np.flatnonzero(readb != '-')[:n]
     isdif = False
-    ev_base = np.array([s[2] for s in modevents['model_state'][start_clip:start_clip + n]], dtype='U1')
+    ev_base = _event_bases(modevents['model_state'][start_clip:start_clip + n])
     bad = np.flatnonzero(readb[aligned] != ev_base)
     if len(bad):                                          # myDetect.py:868-874
         print('Error Does not match', readb[aligned[bad[0]]], ev_base[bad[0]], aligned[bad[0]], bad[0] + start_clip)

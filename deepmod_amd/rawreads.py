@@ -41,8 +41,8 @@ def save_raw_container(path: str, reads: List[Dict]) -> None:
             arrays['r%d_ev_%s' % (i, f)] = np.asarray(ed[f])
         metas.append({'read_id': rd['read_id']})
     arrays['meta'] = np.array(json.dumps(metas))
-    with open(path, 'wb') as fh:
-        np.savez_compressed(fh, **arrays)
+    with open(path, 'wb') as fh:      # uncompressed: inflating the samples was 40 % of a streaming worker's host time
+        np.savez(fh, **arrays)
 
 
 def load_raw_container(path: str) -> List[Dict]:
@@ -55,6 +55,15 @@ def load_raw_container(path: str) -> List[Dict]:
             ed[f] = z['r%d_ev_%s' % (i, f)]
         reads.append({'read_id': m['read_id'], 'raw': z['r%d_raw' % i], 'events_data': ed})
     return reads
+
+
+def event_bases(model_state) -> np.ndarray:
+    """model_state[2] of every event (the basecalled base of a 5-mer state) as a 'U1' array, without a Python loop."""
+    ms = np.ascontiguousarray(model_state)
+    if len(ms) == 0:
+        return np.zeros(0, 'U1')
+    width = ms.dtype.itemsize // 4
+    return ms.view('U1').reshape(len(ms), width)[:, 2]
 
 
 def getEvent(moptions, sp_param):
@@ -76,7 +85,7 @@ def getEvent(moptions, sp_param):
     m_event['length'] = seg_len
     m_event['model_state'] = events_data['model_state'][heads]
     sp_param['m_event'] = m_event
-    sp_param['m_event_basecall'] = ''.join([ms[2] for ms in m_event['model_state']])
+    sp_param['m_event_basecall'] = ''.join(event_bases(m_event['model_state']).tolist())
     sp_param['left_right_skip'] = (0, 0)
 
 

@@ -97,6 +97,7 @@ def map_read(flag: int, pos1: int, cigar: str, readseq: str, refseq, n_events: i
     if out['status'] == _lib.DM_MAP_OK:
         n = int(info[_lib.DM_MAP_N_ROWS])
         out['base_map_info'] = predstore.make_base_map_info(refb[:n].astype('U1'), readb[:n].astype('U1'), refi[:n], readi[:n])
+        out['table_s1'] = (refb[:n], readb[:n], refi[:n].astype(np.int64))      # the same columns as the C walk wrote them (streaming path)
         out.update(leftclip=int(info[_lib.DM_MAP_LEFTCLIP]), rightclip=int(info[_lib.DM_MAP_RIGHTCLIP]),
                    ev_lo=int(info[_lib.DM_MAP_EV_LO]), ev_hi=int(info[_lib.DM_MAP_EV_HI]),
                    first_match_pos=int(info[_lib.DM_MAP_FIRST_MATCH_POS]), last_match_pos=int(info[_lib.DM_MAP_LAST_MATCH_POS]))
@@ -159,7 +160,7 @@ def map_records(moptions, sp_options, sp_param, f5align, f5data):
             continue
         reads.append({'readk': readk, 'readk_ind': readk_ind, 'chr': rname, 'strand': mp['strand'],
                       'mapped_start': f5align[readk][3] - 1, 'start_clip': mp['leftclip'], 'end_clip': mp['rightclip'],
-                      'base_map_info': bmi, 'mfeatures': mfeatures, 'events': events, 'src': f5data[readk][3],
+                      'base_map_info': bmi, 'table_s1': mp['table_s1'], 'mfeatures': mfeatures, 'events': events, 'src': f5data[readk][3],
                       'num_insertions': mp['num_insertions'], 'num_deletions': mp['num_deletions'],
                       'num_mismatches': mp['num_mismatches']})
     return reads

@@ -119,11 +119,14 @@ def rows_from_reads(reads: Iterable[Dict], base: str, src: str, out: Prepared) -
     for rd in reads:
         bmi = rd['base_map_info']
         tx.append(np.asarray(rd['mfeatures'][:, 3:], np.float32))
-        refb.append(bmi['refbase'].astype('S1'))
-        readb.append(bmi['readbase'].astype('S1'))
-        refi.append(bmi['refbasei'].astype(np.int64))
-        ms = rd['events']['model_state']
-        evb.append(np.ascontiguousarray(ms).view('U1').reshape(len(ms), -1)[:, 2].astype('S1') if len(ms) else np.zeros(0, 'S1'))
+        if 'table_s1' in rd:                       # reads that came through dm_map_read carry the byte columns already
+            rb, qb, ri = rd['table_s1']
+            refb.append(rb); readb.append(qb); refi.append(ri)
+        else:
+            refb.append(bmi['refbase'].astype('S1'))
+            readb.append(bmi['readbase'].astype('S1'))
+            refi.append(bmi['refbasei'].astype(np.int64))
+        evb.append(rawreads.event_bases(rd['events']['model_state']).astype('S1'))
         metas.append(rd)
     off = lambda parts: np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
     pk = {'tx': np.concatenate(tx), 'refbase': np.concatenate(refb), 'readbase': np.concatenate(readb),

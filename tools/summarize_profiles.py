@@ -20,5 +20,8 @@ for d in sorted(glob.glob(src + "/pmc_*")):
     for k, v in acc.items():
         out[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v), "mean_kernel_ns_in_this_pass": sum(dur) / len(dur)}
 out["windows_per_launch"] = 65536
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_source_sha: bench.py marks this summary stale once the kernel sources change)
+out["kernel_src_sha"] = bench.kernel_source_sha()
 json.dump(out, open(os.path.join(dest, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps({k: (v["mean_per_launch"] if isinstance(v, dict) else v) for k, v in out.items()}, indent=1))

@@ -73,6 +73,7 @@ SIGNATURES = [
     ("dm_signal_destroy", None, [_vp]),
     ("dm_map_read", _c.c_int, [_c.c_int, _i64, _c.c_char_p, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     ("dm_signal_event_stats", _c.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_i64), _vp]),
+    ("dm_signal_event_stats_batch", _c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 ]
 
 

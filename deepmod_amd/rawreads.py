@@ -101,16 +101,23 @@ def get_Event_Signals(moptions, sp_options, raw_files, normalizer=None):
             sp_options["Error"]["Cannot open fast5 or other errors"].append(f5f)
             print("Cannot open fast5 or other errors: {}".format(f5f))
             continue
+        # events of every read of the container first (host), then ONE device round trip for their signal statistics
+        pending = []
         for rd in reads:
             sp_param = {'mfile_path': f5f, 'f5status': '', 'raw_signals': rd['raw'], 'events_data': rd['events_data'],
                         'read_id': rd['read_id'].replace(" ", ":::").replace("\t", "|||")}
             try:
                 getEvent(moptions, sp_param)
-                if sp_param['f5status'] == '':
-                    dm_signal.mnormalized_event_stats(moptions, sp_param, normalizer)
             except Exception as exc:
                 sp_param['f5status'] = "Cannot open fast5 or other errors"
                 print("Cannot open fast5 or other errors: {} ({})".format(f5f, exc))
+            pending.append(sp_param)
+        ok = [sp for sp in pending if sp['f5status'] == '']
+        for sp, exc in zip(ok, dm_signal.mnormalized_event_stats_batch(moptions, ok, normalizer) if ok else []):
+            if exc is not None:
+                sp['f5status'] = "Cannot open fast5 or other errors"
+                print("Cannot open fast5 or other errors: {} ({})".format(f5f, exc))
+        for sp_param in pending:
             if sp_param['f5status'] == '':
                 if sp_param['read_id'] in f5data:
                     print('Duplicate id', sp_param['read_id'], f5f)

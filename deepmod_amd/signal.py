@@ -56,6 +56,31 @@ class SignalNormalizer:
         return mean, stdv, norm, int(first_empty.value), sig
 
 
+    def event_stats_batch(self, reads):
+        """reads: [(raw int16[n], ev_start uint64[E], ev_length uint64[E])] -> [(mean, stdv, norm dict, first_empty)] with one
+        device round trip for the whole list (dm_signal_event_stats_batch; bit-identical to per-read event_stats)."""
+        if not reads:
+            return []
+        raws = [np.ascontiguousarray(r[0], dtype=np.int16) for r in reads]
+        sts = [np.ascontiguousarray(r[1], dtype=np.uint64) for r in reads]
+        lns = [np.ascontiguousarray(r[2], dtype=np.uint64) for r in reads]
+        raw_off = np.concatenate([[0], np.cumsum([len(r) for r in raws])]).astype(np.int64)
+        ev_off = np.concatenate([[0], np.cumsum([len(t) for t in sts])]).astype(np.int64)
+        raw = np.concatenate(raws)
+        st, ln = np.concatenate(sts), np.concatenate(lns)
+        n = len(reads)
+        mean = np.empty(len(st), np.float32)
+        stdv = np.empty(len(st), np.float32)
+        norm6 = np.empty((n, 6), np.float64)
+        first_empty = np.empty(n, np.int64)
+        _lib.check(self._lib.dm_signal_event_stats_batch(self._h, n, raw.ctypes.data, raw_off.ctypes.data, st.ctypes.data, ln.ctypes.data,
+                                                         ev_off.ctypes.data, mean.ctypes.data, stdv.ctypes.data, norm6.ctypes.data,
+                                                         first_empty.ctypes.data))
+        keys = ("mshift", "mscale", "read_med", "read_mad", "lower_lim", "upper_lim")
+        return [(mean[ev_off[i]:ev_off[i + 1]], stdv[ev_off[i]:ev_off[i + 1]], dict(zip(keys, norm6[i].tolist())), int(first_empty[i]))
+                for i in range(n)]
+
+
 _default: Optional[SignalNormalizer] = None
 
 
@@ -75,10 +100,22 @@ def mnormalized_event_stats(moptions, sp_param, normalizer: Optional[SignalNorma
             _default = SignalNormalizer(int(moptions.get('device', 0)) if hasattr(moptions, 'get') else 0)
         normalizer = _default
     ev = sp_param['m_event']
+    _check_event_span(sp_param)
+    mean, stdv, norm, first_empty, sig = normalizer.event_stats(sp_param['raw_signals'], ev['start'], ev['length'], want_signal)
+    return _apply_event_stats(sp_param, mean, stdv, norm, first_empty, sig if want_signal else None)
+
+
+def _check_event_span(sp_param):
+    ev = sp_param['m_event']
     if not ev['start'][0] < (ev['start'][-1] + ev['length'][-1]):
         print('Fatal error signal start position is less than the end position', sp_param.get('mfile_path'),
               ev['start'][0], ev['start'][-1], ev['length'][-1])
-    mean, stdv, norm, first_empty, sig = normalizer.event_stats(sp_param['raw_signals'], ev['start'], ev['length'], want_signal)
+
+
+def _apply_event_stats(sp_param, mean, stdv, norm, first_empty, sig=None):
+    """Write the device results into sp_param['m_event'] with the reference's handling of an empty event slice."""
+    ev = sp_param['m_event']
+    want_signal = sig is not None
     n_ok = first_empty
     ev['mean'][:n_ok] = mean[:n_ok]
     ev['stdv'][:n_ok] = stdv[:n_ok]
@@ -92,3 +129,31 @@ def mnormalized_event_stats(moptions, sp_param, normalizer: Optional[SignalNorma
     if want_signal:
         sp_param['raw_signals'] = sig
     return sp_param
+
+
+def mnormalized_event_stats_batch(moptions, sp_params, normalizer: Optional[SignalNormalizer] = None):
+    """mnormalized_event_stats for a list of reads with one device round trip (reads of a worker batch travel together: a
+    single 120 k-sample read is launch / latency bound).  Same sp_param contract per read; a read the batched call
+    cannot take (events covering no signal) makes the whole list fall back to per-read calls, so that only that read fails."""
+    global _default
+    if normalizer is None:
+        if _default is None:
+            _default = SignalNormalizer(int(moptions.get('device', 0)) if hasattr(moptions, 'get') else 0)
+        normalizer = _default
+    for sp in sp_params:
+        _check_event_span(sp)
+    try:
+        res = normalizer.event_stats_batch([(sp['raw_signals'], sp['m_event']['start'], sp['m_event']['length']) for sp in sp_params])
+    except _lib.DeepModHipError:
+        res = None
+    out = []
+    for i, sp in enumerate(sp_params):
+        try:
+            if res is None:
+                mnormalized_event_stats(moptions, sp, normalizer)
+            else:
+                _apply_event_stats(sp, *res[i])
+            out.append(None)
+        except Exception as exc:          # reported per read by the caller
+            out.append(exc)
+    return out

@@ -216,6 +216,14 @@ int dm_signal_event_stats(dm_signal* s, const int16_t* raw, int64_t n_raw, const
                           const uint64_t* ev_length, int64_t n_events, float* ev_mean, float* ev_stdv, double* norm6,
                           int64_t* first_empty, double* normalized);
 
+/* Many reads per call (a typical 120 k-sample read is launch / latency bound when it travels alone): the reads' samples back to
+ * back in raw (read r = raw[raw_off[r] .. raw_off[r+1])), event tables back to back (events of read r = [ev_off[r], ev_off[r+1]),
+ * starts relative to the read's first sample); norm6 [n_reads][6] and first_empty [n_reads] optional.  Host arrays only.
+ * Bit-identical to n_reads calls of dm_signal_event_stats. */
+int dm_signal_event_stats_batch(dm_signal* s, int64_t n_reads, const int16_t* raw, const int64_t* raw_off, const uint64_t* ev_start,
+                                const uint64_t* ev_length, const int64_t* ev_off, float* ev_mean, float* ev_stdv, double* norm6,
+                                int64_t* first_empty);
+
 /* ---- SAM record -> per-base alignment table (host code, no GPU needed) ---------------------
  * Replaces the alignment walk of handle_record, myDetect.py:515-714: clip stripping, one row per M/I/D/N/=/X
  * position, first/last-match trimming of table and event slice, '-' strand flip + complement, the CpG gap swap.

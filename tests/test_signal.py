@@ -120,3 +120,50 @@ def test_hip_device_resident_signal_and_errors():
         nz.event_stats(raw.astype(np.float32), start, length)
     d_raw.free()
     nz.close()
+
+
+@pytest.mark.gpu
+def test_batched_call_is_bit_identical_to_per_read_calls():
+    """dm_signal_event_stats_batch (all reads of a worker batch in one device round trip) against n per-read calls:
+    every mean / stdv / median / limit bit for bit, the first-empty index of a read whose last events run off its
+    signal, and the per-read fallback when one read of the list cannot be processed."""
+    from deepmod_amd import _lib, signal
+    cases = [_random_case(20 + i, n, ml) for i, (n, ml) in enumerate([(120_000, 9.0), (65_536, 2.0), (300_000, 300.0), (90_001, 11.0),
+                                                                      (1_000_003, 10.0), (7_000, 5.0)])]
+    raw, start, length = cases[3]
+    start, length = start.copy(), length.copy()
+    length[-3:] = 50                                                   # the last events end past the signal / start at its end
+    start[-1] = np.uint64(len(raw))
+    cases[3] = (raw, start, length)
+    nz = signal.SignalNormalizer(0)
+    single = [nz.event_stats(r, s, l) for r, s, l in cases]
+    batch = nz.event_stats_batch(cases)
+    assert len(batch) == len(cases)
+    for (m1, s1, n1, f1, _), (m2, s2, n2, f2) in zip(single, batch):
+        assert f1 == f2
+        assert n1 == n2
+        assert _same_f32(m1, m2) and _same_f32(s1, s2)
+    assert batch[3][3] == len(cases[3][1]) - 1 and np.isnan(batch[3][0][-1])
+    # the sp_param-level entry: same event tables as the per-read entry, including the error isolation
+    def params():
+        out = []
+        for i, (r, s, l) in enumerate(cases):
+            ev = np.zeros(len(s), dtype=EVENT_DTYPE)
+            ev['start'], ev['length'] = s, l
+            out.append({'raw_signals': r, 'm_event': ev, 'mfile_path': 'case%d' % i})
+        return out
+    a, b = params(), params()
+    for sp in a:
+        signal.mnormalized_event_stats({}, sp, nz)
+    errs = signal.mnormalized_event_stats_batch({}, b, nz)
+    assert errs == [None] * len(cases)
+    for x, y in zip(a, b):
+        assert len(x['m_event']) == len(y['m_event'])
+        assert _same_f32(x['m_event']['mean'], y['m_event']['mean']) and _same_f32(x['m_event']['stdv'], y['m_event']['stdv'])
+        assert x['norm'] == y['norm']
+    c = params()
+    c[2]['m_event']['start'] += np.uint64(10 ** 9)                     # this read's events cover no signal
+    errs = signal.mnormalized_event_stats_batch({}, c, nz)
+    assert isinstance(errs[2], _lib.DeepModHipError) and all(e is None for i, e in enumerate(errs) if i != 2)
+    assert _same_f32(c[0]['m_event']['mean'], a[0]['m_event']['mean']) and _same_f32(c[5]['m_event']['stdv'], a[5]['m_event']['stdv'])
+    nz.close()

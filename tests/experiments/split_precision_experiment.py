@@ -75,6 +75,26 @@ def make_matmul(mode):
             qa = lambda t: mx_quant(t, 1, **F)     # blocks along K of A [n, K]
             qw = lambda t: mx_quant(t, 0, **F)     # blocks along K of W [K, N]
             return out + qa(a_lo) @ qw(w_hi) + qa(a_hi) @ qw(w_lo)
+        if mode == "i8cross":
+            # both cross terms as ONE int8 product with int32 accumulation (v_mfma_i32_16x16x64_i8 runs at twice the f16 rate):
+            #   [a_lo | a_hi] . [w_hi ; w_lo] in fixed point - activations against a global scale (|h| < 1, |h_lo| <= 2^-12; other
+            #   inputs against their row maximum), weights against their column maximum; lo scales = 2^-12 x hi scales so that
+            #   the two products share one scale and one accumulator
+            nx = 7 if a.shape[1] == 107 else 0                                               # layer 0: the 7 raw features keep the f16 cross terms
+            sw = np.abs(w_hi[nx:]).max(axis=0, keepdims=True)                                # per gate column
+            sw = np.where(sw > 0, sw, 1.0)
+            q = lambda t, sc: np.clip(np.rint(t / sc * 127.0), -127, 127)
+            cross = q(a_lo[:, nx:], 2.0 ** -11) @ q(w_hi[nx:], sw) + q(a_hi[:, nx:], 1.0) @ q(w_lo[nx:], sw * 2.0 ** -11)
+            return out + cross * (sw * 2.0 ** -11 / (127.0 * 127.0)) + a_lo[:, :nx] @ w_hi[:nx] + a_hi[:, :nx] @ w_lo[:nx]
+        if mode in ("i8cross_alo", "i8cross_ahi"):     # only one of the two cross terms in int8, the other in f16
+            nx = 7 if a.shape[1] == 107 else 0
+            sw = np.abs(w_hi[nx:]).max(axis=0, keepdims=True)
+            sw = np.where(sw > 0, sw, 1.0)
+            q = lambda t, sc: np.clip(np.rint(t / sc * 127.0), -127, 127)
+            xpart = a_lo[:, :nx] @ w_hi[:nx] + a_hi[:, :nx] @ w_lo[:nx]
+            if mode == "i8cross_alo":
+                return out + xpart + (q(a_lo[:, nx:], 2.0 ** -11) @ q(w_hi[nx:], sw)) * (sw * 2.0 ** -11 / (127.0 * 127.0)) + a_hi[:, nx:] @ w_lo[nx:]
+            return out + xpart + a_lo[:, nx:] @ w_hi[nx:] + (q(a_hi[:, nx:], 1.0) @ q(w_lo[nx:], sw * 2.0 ** -11)) * (sw * 2.0 ** -11 / (127.0 * 127.0))
         if mode == "e4m3cross_full":               # cross terms from the FULL operand: a_lo*w + a*w_lo - drops nothing extra
             qa = lambda t: mx_quant(t, 1, **E4M3)
             qw = lambda t: mx_quant(t, 0, **E4M3)
@@ -112,10 +132,10 @@ def predict(weights, x, mm):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     x = synth.synthetic_windows(n, seed=3)
-    modes = ["f16x3", "bf16cross", "e4m3cross", "e4m3cross_full", "e5m2cross", "f16x1"]
+    modes = ["f16x3", "bf16cross", "i8cross", "i8cross_alo", "i8cross_ahi", "e4m3cross", "e5m2cross", "f16x1"]
     print("max |dp| vs the fp32 restatement, %d windows (tolerance of the path: 1e-4)" % n)
     print("%-8s" % "scale" + "".join("%16s" % m for m in modes))
-    for scale in (1.0, 4.0, 16.0):
+    for scale in (1.0, 4.0) + ((16.0,) if os.environ.get('DM_EXP_SCALE16') else ()):
         for seed in (7, 26):
             w = synth.synthetic_weights(seed, scale)
             ref = predict(w, x, make_matmul("fp32"))

@@ -255,6 +255,22 @@ def test_region_and_contig_filters(golden, hip_lib):
     assert set(names({'region': [['chrS', None, 1500]]})) <= {'plain_fwd', 'plain_rev', 'cpg_swap_fwd', 'cpg_swap_rev'}
 
 
+def test_no_match_diagnostics_print_at_the_default_warning_level(golden, hip_lib, capsys):
+    """myCom.OUTPUT_WARNING is 2 = the default --outLevel: the reference prints 'Errorfast5' / 'match-Error!!!' for a read without a
+    first / last match at that level (myDetect.py:617-622) and stays silent at outLevel 3."""
+    f5data, f5align = _inputs(golden)
+    only = {'no_match': f5align['no_match']}
+    for level, expect in ((2, True), (3, False)):
+        sp_options = defaultdict()
+        sp_options.update({'Mod': [], 'Error': defaultdict(list)})
+        sp_param = defaultdict()
+        sp_param.update({'f5data': f5data, 'ref_info': {'chrS': golden['genome']}, 'f5status': '', 'line': ''})
+        mo = {'ConUnk': True, 'outLevel': level, 'fnum': 7, 'windowsize': 21, 'region': [[None, None, None]]}
+        assert readmap.map_records(mo, sp_options, sp_param, only, f5data) == []
+        out = capsys.readouterr().out
+        assert ('Errorfast5' in out and 'match-Error!!! no first and/or last match' in out) == expect
+
+
 def test_raw_batch_without_alignment_goes_to_error_channel(tmp_path, hip_lib, monkeypatch):
     """No aligner on PATH and no side-car SAM -> every read of the batch is reported under the reference's key."""
     from deepmod_amd import synth_reads

@@ -99,14 +99,15 @@ def cpu_baseline(weights, x_sample_src):
             "single_thread": {"value": one, "cores": 1, "sample": "%d windows in %.1f s" % (n_one, dt_one)}}
 
 
-def kernel_source_sha():
-    """Hash of the classifier kernel sources: a PMC summary is only valid for the sources it was collected on."""
+KERNEL_SOURCES = {"f16x3": ["lstm_f16.hip.inc"], "f32": ["lstm_f32.hip.inc"]}
+
+
+def kernel_source_sha(precision):
+    """Hash of the classifier kernel's source: a PMC summary is only valid for the kernel it was collected on."""
     import hashlib
     h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "deepmod_amd", "csrc")
-    for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".inc")):
-            h.update(open(os.path.join(csrc, f), "rb").read())
+    for f in KERNEL_SOURCES[precision]:
+        h.update(open(os.path.join(ROOT, "deepmod_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -128,8 +129,8 @@ def measured_traffic(precision):
             continue
         return {"bytes": 2.0 * fetch + write, "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
                 "source": os.path.relpath(path, ROOT), "windows_per_launch": pmc.get("windows_per_launch", BATCH),
-                "profiled_kernel_src_sha": pmc.get("kernel_src_sha"), "kernel_src_sha": kernel_source_sha(),
-                "stale": pmc.get("kernel_src_sha") != kernel_source_sha()}
+                "profiled_kernel_src_sha": pmc.get("kernel_src_sha"), "kernel_src_sha": kernel_source_sha(precision),
+                "stale": pmc.get("kernel_src_sha") != kernel_source_sha(precision)}
     return None
 
 

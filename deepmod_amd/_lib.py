@@ -66,6 +66,7 @@ SIGNATURES = [
     ("dm_summary_fetch", _c.c_int, [_vp, _vp, _vp, _vp]),
     ("dm_summary_device_ptr", _vp, [_vp]),
     ("dm_summary_follow", _c.c_int, [_vp, _vp]),
+    ("dm_bed_format", _i64, [_c.c_char_p, _c.c_char, _c.c_char, _vp, _vp, _vp, _i64, _vp, _i64]),
     ("dm_cluster_create", _vp, [_c.c_int, _vp, _c.c_size_t]),
     ("dm_cluster_destroy", None, [_vp]),
     ("dm_cluster_predict", _c.c_int, [_vp, _vp, _i64, _vp]),

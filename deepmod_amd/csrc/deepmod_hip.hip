@@ -1377,3 +1377,4 @@ int dm_summary_grow(dm_summary* s, int64_t new_length) {
 
 #include "signal.hip.inc"
 #include "readmap.inc"
+#include "bedtext.inc"

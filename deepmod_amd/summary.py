@@ -95,7 +95,25 @@ class PositionSummary:
 def bed_lines(chrom: str, strand: str, base: str, touch: np.ndarray, cov: np.ndarray, mod: np.ndarray) -> bytes:
     """BED text exactly as the reference writes it (myDetect.py:1112-1120): one line per position
     whose key was created (touch > 0), sorted by position, single spaces, trailing space before the
-    newline, column 5 = min(cov, 1000), pct = trunc(100*mod/max(cov,1))."""
+    newline, column 5 = min(cov, 1000), pct = trunc(100*mod/max(cov,1)).  Formatted by dm_bed_format (host C)."""
+    lib = _lib.load()
+    touch = np.ascontiguousarray(touch, np.int32)
+    cov = np.ascontiguousarray(cov, np.int32)
+    mod = np.ascontiguousarray(mod, np.int32)
+    n = len(touch)
+    args = (chrom.encode("ascii"), strand.encode("ascii"), base.encode("ascii"), touch.ctypes.data, cov.ctypes.data, mod.ctypes.data, n)
+    bound = lib.dm_bed_format(*args, None, 0)
+    if bound < 0:
+        raise _lib.DeepModHipError("dm_bed_format: " + _lib.last_error())
+    buf = np.empty(max(int(bound), 1), np.uint8)
+    got = lib.dm_bed_format(*args, buf.ctypes.data, int(bound))
+    if got < 0 or got > bound:
+        raise _lib.DeepModHipError("dm_bed_format: " + _lib.last_error())
+    return buf[:got].tobytes()
+
+
+def bed_lines_py(chrom: str, strand: str, base: str, touch: np.ndarray, cov: np.ndarray, mod: np.ndarray) -> bytes:
+    """The same text from a Python loop (a line-by-line restatement of the reference's writer; tests compare the two)."""
     idx = np.flatnonzero(touch > 0)
     out = []
     for pos, cv, md in zip(idx.tolist(), cov[idx].tolist(), mod[idx].tolist()):

@@ -184,6 +184,13 @@ void* dm_summary_device_ptr(dm_summary* s);
  * before destroying the model. */
 int dm_summary_follow(dm_summary* s, dm_model* m);
 
+/* BED text of one contig x strand from the (host) counters, byte for byte what sum_handler writes (myDetect.py:1107-1120):
+ * one line per position with touch > 0, "<chr> <pos> <pos+1> <Base> <min(cov,1000)> <strand> <pos> <pos+1> 0,0,0 <cov> <pct> <mod> \n".
+ * Returns the length of the text.  With out == NULL or cap below the safe bound (lines * (strlen(chrom) + 128)) nothing is written and
+ * that bound is returned: allocate it and call again. */
+int64_t dm_bed_format(const char* chrom, char strand, char base, const int32_t* touch, const int32_t* cov, const int32_t* mod,
+                      int64_t length, char* out, int64_t cap);
+
 /* ------------------------------------------------------------- CpG cluster second stage -- */
 /*
  * MLP 14 -> 100 (relu) -> 20 (relu) -> 1 (sigmoid) of DeepMod_tools/hm_cluster_predict.py:94-103,:161

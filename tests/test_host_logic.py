@@ -160,3 +160,34 @@ def test_generate_motif_pos_matches_reference_tool(tmp_path):
     assert sorted(os.listdir(tmp_path / "out")) == sorted(g['outputs'])
     for fn, text in g['outputs'].items():
         assert (tmp_path / "out" / fn).read_text() == text, fn
+
+
+def test_c_bed_writer_equals_line_by_line_restatement(hip_lib):
+    """dm_bed_format (host C) against the Python restatement of the reference's writer (myDetect.py:1112-1120), and both
+    against the bytes the reference's own sum_handler produced (host_sum_handler.json)."""
+    import json
+    from deepmod_amd import summary
+    rng = np.random.default_rng(7)
+    n = 200_000
+    touch = ((rng.random(n) < 0.3) * rng.integers(1, 2000, n)).astype(np.int32)
+    cov = np.where(touch > 0, rng.integers(0, 2500, n), 0).astype(np.int32)
+    cov[rng.random(n) < 0.02] = 0                                   # deletion-only positions: cov = 0 lines
+    mod = np.minimum(cov, rng.integers(0, 2500, n)).astype(np.int32)
+    for chrom in ("chr1", "NC_000913.3", "x"):
+        assert summary.bed_lines(chrom, "+", "C", touch, cov, mod) == summary.bed_lines_py(chrom, "+", "C", touch, cov, mod)
+    z = np.zeros(10, np.int32)
+    assert summary.bed_lines("c", "-", "A", z, z, z) == b""
+    one = np.array([0, 3, 0], np.int32)
+    assert summary.bed_lines("c", "-", "A", one, np.array([0, 1001, 0], np.int32), np.array([0, 7, 0], np.int32)) == \
+        b"c 1 2 A 1000 - 1 2 0,0,0 1001 0 7 \n"
+    case = json.load(open(os.path.join(GOLDEN, "host_sum_handler.json")))[0]
+    length = 1 + max(max(r["refbasei"]) for r in case["reads"])
+    counts = [np.zeros(length, np.int32) for _ in range(3)]
+    for r in case["reads"]:
+        for rb, qb, pos, mp in zip(r["refbase"], r["readbase"], r["refbasei"], r["mod_pred"]):
+            if rb == case["Base"]:
+                counts[0][pos] += 1
+                if qb != '-':
+                    counts[1][pos] += 1
+                    counts[2][pos] += int(mp == 1)
+    assert summary.bed_lines(case["chr"], case["strand"], case["Base"], *counts) == case["bed"].encode("ascii")

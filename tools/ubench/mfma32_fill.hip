@@ -21,6 +21,8 @@ template <> struct Acc<32> { typedef floatx16 T; };
 template <> struct Acc<16> { typedef floatx4 T; };
 template <> struct Acc<3200> { typedef floatx16 T; };   // 32x32x16 bf16 (same operand bits reinterpreted): does the narrower multiplier draw less power?
 template <> struct Acc<1600> { typedef floatx4 T; };    // 16x16x32 bf16
+template <> struct Acc<1605> { typedef floatx4 T; };    // 16x16x32 f16, low 5 mantissa bits of every operand zero (does a shorter lo half draw less power?)
+template <> struct Acc<1608> { typedef floatx4 T; };    // 16x16x32 f16, low 8 mantissa bits zero
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int SHAPE>
@@ -28,7 +30,7 @@ __device__ __forceinline__ typename Acc<SHAPE>::T mfma(halfx8 a, halfx8 b, typen
     if constexpr (SHAPE == 32) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     else if constexpr (SHAPE == 3200) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     else if constexpr (SHAPE == 1600) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);       // 16, 1605, 1608
 }
 
 template <int SHAPE, int NACC, int CHAIN, int NV, int NT, int NDS, int GROUPS>
@@ -45,6 +47,14 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
             a[j][i] = (_Float16)(0.37f * float(((lane * 7 + i * 13 + j * 29) % 61) - 30) / 30.f);
             b[j][i] = (_Float16)(0.41f * float(((lane * 11 + i * 5 + j * 3) % 53) - 26) / 26.f);
         }
+    if (SHAPE == 1605 || SHAPE == 1608) {
+        const unsigned short msk = SHAPE == 1605 ? 0xFFE0 : 0xFF00;
+        for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 8; ++i) {
+                a[j][i] = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, a[j][i]) & msk));
+                b[j][i] = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, b[j][i]) & msk));
+            }
+    }
     float v[8], e[4];
     for (int i = 0; i < 8; ++i) v[i] = 0.001f * (threadIdx.x + i);
     for (int i = 0; i < 4; ++i) e[i] = 0.01f * (lane + i);
@@ -129,7 +139,7 @@ int main() {
     run<SHAPE, NACC, CHAIN, NV, NT, NDS>(#SHAPE " acc=" #NACC " chain=" #CHAIN " valu=" #NV " trans=" #NT " ds/group=" #NDS, 4, d, dc); \
     run<SHAPE, NACC, CHAIN, NV, NT, NDS>(#SHAPE " acc=" #NACC " chain=" #CHAIN " valu=" #NV " trans=" #NT " ds/group=" #NDS, 8, d, dc);
     // bare MFMA streams
-    R(3200, 1, 3, 0, 0, 0) R(1600, 1, 3, 0, 0, 0)
+    R(3200, 1, 3, 0, 0, 0) R(1600, 1, 3, 0, 0, 0) R(16, 1, 3, 0, 0, 0) R(1605, 1, 3, 0, 0, 0) R(1608, 1, 3, 0, 0, 0) R(16, 1, 3, 0, 0, 0) R(1605, 1, 3, 0, 0, 0) R(1608, 1, 3, 0, 0, 0)
     R(32, 1, 3, 0, 0, 0) R(32, 2, 3, 0, 0, 0) R(32, 3, 1, 0, 0, 0) R(16, 1, 3, 0, 0, 0) R(16, 3, 1, 0, 0, 0)
     // plain VALU fillers between chained MFMAs (same accumulator) and between rotating accumulators
     R(32, 1, 3, 1, 0, 0) R(32, 1, 3, 2, 0, 0) R(32, 1, 3, 3, 0, 0) R(32, 1, 3, 4, 0, 0) R(32, 1, 3, 5, 0, 0) R(32, 1, 3, 6, 0, 0)

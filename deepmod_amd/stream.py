@@ -439,6 +439,10 @@ def stream_rank_main(moptions, rank: int, world: int, device: int, work, result_
     """Body of one GPU process.  `work`: a shared queue of (files, subfolder, batchid) items drained by all ranks,
     or a list of file lists (static shard).  Returns / posts {'errors', 'stats'}."""
     from . import comm as dmcomm, signal as dmsignal
+    communicator = rdv = None
+    if world > 1:       # collectively, before any work: a rank that cannot join fails the run at once, not after its share of the reads
+        rdv = dmcomm.FileRendezvous(os.path.join(moptions['outFolder'], '.rendezvous'), rank, world)
+        communicator = dmcomm.Communicator.from_rendezvous(device, rdv)
     backend = HipBackend(moptions, device)
     eng = StreamEngine(moptions, backend, rank, world)
     if moptions.get('Ref') and os.path.isfile(moptions['Ref']):
@@ -446,10 +450,7 @@ def stream_rank_main(moptions, rank: int, world: int, device: int, work, result_
         eng.set_reference_lengths({c: len(s) for c, s in readmap.read_fasta(moptions['Ref']).items()})
     batches = _drain(work) if hasattr(work, 'get') else iter(work)
     eng.run(batches, feeders=feeders, make_normalizer=lambda: dmsignal.SignalNormalizer(device))
-    communicator = None
-    if world > 1:
-        rdv = dmcomm.FileRendezvous(os.path.join(moptions['outFolder'], '.rendezvous'), rank, world)
-        communicator = dmcomm.Communicator.from_rendezvous(device, rdv)
+    if communicator is not None:
         gather = lambda obj: rdv.all_gather_json('summary_keys', obj)
         reduce_fn = lambda s: s.reduce(communicator, 0)
     else:

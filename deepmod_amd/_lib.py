@@ -14,6 +14,7 @@ DM_OPT_PRECISION = 2
 DM_OPT_ASYNC = 3
 DM_PREC_F32 = 0
 DM_PREC_F16X3 = 1
+DM_PREC_F16X3S = 3   # step-major tile-major split-f16 kernel (lstm_f16s.hip.inc)
 DM_PREC_F16X3T = 2   # dev builds with -DDM_EXPERIMENT_F16T only (tools/experiments/f16t)
 DM_INFO_PRECISION, DM_INFO_F16_REPRESENTABLE, DM_INFO_F16_LENGTH_SHIFT, DM_INFO_DEVICE = 1, 2, 3, 4
 DM_OK, DM_EINVAL, DM_EDEVICE, DM_ENOMEM, DM_ESTATE, DM_ERCCL, DM_ERANGE = 0, -1, -2, -3, -4, -5, -6

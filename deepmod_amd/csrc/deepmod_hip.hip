@@ -17,6 +17,7 @@
 #include "../../include/deepmod_hip.h"
 #include "lstm_f32.hip.inc"
 #include "lstm_f16.hip.inc"
+#include "lstm_f16s.hip.inc"
 #ifdef DM_EXPERIMENT_F16T   // tools/experiments/f16t: tile-major split-f16 kernel (parity-clean, same speed: profiles/r02/README.md); dev builds only
 #include "lstm_f16t.hip.inc"
 #endif
@@ -27,6 +28,7 @@
 #define DM16_TRACE2_LDS 0
 #endif
 
+#define DM_PREC_F16X3S 3   /* step-major tile-major split-f16 kernel (lstm_f16s.hip.inc) */
 #define DM_PREC_F16X3T 2   /* DM_EXPERIMENT_F16T builds: the tile-major kernel of tools/experiments/f16t */
 
 namespace {
@@ -211,16 +213,15 @@ Packed16 pack_weights_f16(const float* flat) {
     return P;
 }
 
-#ifdef DM_EXPERIMENT_F16T
-// tile-major split-f16 packing (lstm_f16t.hip.inc): [dir][layer][tile][k16-step][hi|lo][lane][8 x f16].
+// tile-major split-f16 packing (lstm_f16s.hip.inc; tools/experiments/f16t uses the same): [dir][layer][tile][k16-step][hi|lo][lane][8 x f16].
 // A-operand lane l of record (tile T, k16-step t): gate row m = l % 32 -> unit 8T + m / 4, gate m % 4;
 // k = (half = l / 32, j = 0..7) -> K slot of the B operand the kernel builds in registers:
 //   t < 6 : own unit 8 (2t + j/4) + 2 (j%4) + half
 //   t == 6: j < 4: own unit 96 + 2j + half (slot 100 = the constant 1.0 -> bias row; 101..103 zero);
 //           j >= 4: layer 0: feature 2 (j-4) + half (7 = event length x 2^-len_shift); layers 1, 2: input unit 96 + 2 (j-4) + half
 //   t > 6 : input unit 8 (2 (t-7) + j/4) + 2 (j%4) + half
-Packed16 pack_weights_f16t(const float* flat) {
-    using namespace lstm16t;
+Packed16 pack_weights_tile(const float* flat) {
+    using namespace lstm16s;
     Packed16 P;
     P.w.assign(WEIGHT_BYTES, 0);
     P.len_shift = choose_len_shift(flat);
@@ -281,8 +282,6 @@ Packed16 pack_weights_f16t(const float* flat) {
     }
     return P;
 }
-
-#endif  // DM_EXPERIMENT_F16T
 
 // ---------------------------------------------------------------------------------------------
 // summary kernel: dense int32 counters with a wavefront-level pre-reduction.
@@ -390,6 +389,7 @@ struct dm_model {
     float* d_bpack = nullptr;
     float* d_hpack = nullptr;
     unsigned char* d_wpack16 = nullptr;   // split-f16 weights (DM_PREC_F16X3)
+    unsigned char* d_wpack16s = nullptr;  // tile-major split-f16 weights (lstm_f16s.hip.inc)
     unsigned char* d_wpack16t = nullptr;  // split-f16 weights of the experimental tile-major kernel (DM_EXPERIMENT_F16T builds)
     float* d_wout = nullptr;              // head W[200][2] fp32 (DM_PREC_F16X3)
     float* d_scratch = nullptr;
@@ -491,12 +491,24 @@ int ensure_f16(dm_model* m) {
     return DM_OK;
 }
 
+int ensure_f16s(dm_model* m) {
+    if (m->d_wpack16s) return DM_OK;
+    int rc = ensure_f16(m);          // representability check, head weights, len_shift
+    if (rc) return rc;
+    Packed16 P = pack_weights_tile(m->host_weights.data());
+    HIP_TRY(hipMalloc(&m->d_wpack16s, P.w.size()));
+    HIP_TRY(hipMemcpy(m->d_wpack16s, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16s::bilstm_f16s_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16s::LDS_BYTES)));
+    return DM_OK;
+}
+
 #ifdef DM_EXPERIMENT_F16T
 int ensure_f16t(dm_model* m) {
     if (m->d_wpack16t) return DM_OK;
     int rc = ensure_f16(m);          // representability check, head weights, len_shift
     if (rc) return rc;
-    Packed16 P = pack_weights_f16t(m->host_weights.data());
+    Packed16 P = pack_weights_tile(m->host_weights.data());
     HIP_TRY(hipMalloc(&m->d_wpack16t, P.w.size()));
     HIP_TRY(hipMemcpy(m->d_wpack16t, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16t::bilstm_f16t_kernel),
@@ -527,6 +539,30 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         ++m->events_used;
         HIP_TRY(hipEventRecord(e0, m->stream));
     }
+    if (m->precision == DM_PREC_F16X3S) {
+        using namespace lstm16s;
+        int rc = ensure_f16s(m);
+        if (rc) return rc;
+        Params p;
+        p.wpack = m->d_wpack16s;
+        p.hpack = m->d_wout;
+        p.bout0 = m->bout[0];
+        p.bout1 = m->bout[1];
+        p.x = d_x;
+        p.xstride = xstride;
+        p.n = n;
+        p.ntiles = int((n + TILE_M - 1) / TILE_M);
+        int rcp = ensure_plogit(m, p.ntiles);
+        if (rcp) return rcp;
+        p.plogit = m->d_plogit;
+        p.len_scale = std::ldexp(1.0f, -m->len_shift);
+        p.range_flag = m->d_range_flag;
+        const int grid = std::min(2 * p.ntiles, m->grid_cap);
+        hipLaunchKernelGGL(bilstm_f16s_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
+        const long long npad = (long long)p.ntiles * TILE_M;
+        hipLaunchKernelGGL(lstm16::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
+                           npad, m->bout[0], m->bout[1], d_prob, d_cls);
+    } else
 #ifdef DM_EXPERIMENT_F16T
     if (m->precision == DM_PREC_F16X3T) {
         using namespace lstm16t;
@@ -827,6 +863,7 @@ void dm_model_destroy(dm_model* m) {
     (void)hipFree(m->d_hpack);
     (void)hipFree(m->d_scratch);
     (void)hipFree(m->d_wpack16);
+    (void)hipFree(m->d_wpack16s);
     (void)hipFree(m->d_wpack16t);
     (void)hipFree(m->d_wout);
     (void)hipFree(m->d_dbg);
@@ -851,6 +888,10 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
             m->async = value != 0;
             return DM_OK;
         case DM_OPT_PRECISION:
+            if (value == DM_PREC_F16X3S && m->f16_ok) {
+                m->precision = int(value);
+                return DM_OK;
+            }
 #ifdef DM_EXPERIMENT_F16T
             if (value == DM_PREC_F16X3T && m->f16_ok) {
                 m->precision = int(value);

@@ -21,6 +21,8 @@ VARIANTS = {
     "noldsb_nz": ["-DDM16_ABL_NOLDSB", "-DDM16_ABL_NOLDSB_NONZERO"],
     "defer": ["-DDM16_DEFER"], "defer_trace": ["-DDM16_DEFER", "-DDM_TRACE"],
     "piece2": ["-DDM16_PIECE_EVERY=2"], "piece3": ["-DDM16_PIECE_EVERY=3"],
+    "prod1": ["-DDM16_ABL_1PROD"], "noseq16": ["-DDM16_ABL_NOSEQ"],
+    "floor16": ["-DDM16_ABL_1PROD", "-DDM16_ABL_NOCELL", "-DDM16_ABL_NOSEQ", "-DDM16_ABL_NODMA", "-DDM16_ABL_NOBAR", "-DDM16_ABL_NOLDSB", "-DDM16_ABL_NOLDSB_NONZERO"],
     "prod2": ["-DDM16_ABL_2PROD"], "nocell16": ["-DDM16_ABL_NOCELL"], "prod2_nocell": ["-DDM16_ABL_2PROD", "-DDM16_ABL_NOCELL"],
     "trace": ["-DDM_TRACE"],                                   # f16x3 kernel: per-wave timeline of one stage
     "w4": ["-DDM16_WAVES=4", "-DDM16_MT=2"],                   # f16x3 kernel: 4 waves x 2 M-tiles (one wave per SIMD)

@@ -30,12 +30,17 @@ N_BATCHES = 16                # 16 x 65,536 = 1,048,576 windows ("10^6 windows b
 FLOP_PER_WINDOW = 8.924e6     # 11 live steps x 2 dirs x 3 layers + head
 # /opt/skills/guides/MI355X_MICROARCH.md dense MFMA peaks: v_mfma_f32_16x16x4_f32 157.3 TF, 16-bit (f16/bf16) 2.5 PF
 PRECISIONS = {
-    "f16x3": {"peak": 2500.0, "kernel": "lstm16::bilstm_f16x3_kernel", "dtype": "f16x3",
-              "label": "split-f16 MFMA (hi+lo f16 operands, 3 products per fp32 product, fp32 accumulate)",
-              "peak_note": "v_mfma_f32_16x16x32_f16 dense 16-bit peak 2.5 PF; the split issues 3 products x 576/507 K padding = "
-                           "3.41 matrix FLOP per algorithmic FLOP, so frac <= 0.293 by construction; a pure MFMA loop on "
-                           "non-zero data sustains 2.0-2.1 PF on this part (2.03 GHz, profiles/r01/ubench_mfma_zero.txt)",
-              "issued_per_algorithmic": 3.0 * 576.0 / 507.0},
+    "f16x3": {"peak": 2500.0, "kernel": "lstm16s::bilstm_f16s_kernel", "dtype": "f16x3",
+              "label": "split-f16 MFMA (hi+lo f16 operands, 3 products per fp32 product, fp32 accumulate), step-major: "
+                       "the state of all three layers stays on the chip",
+              "peak_note": "v_mfma_f32_32x32x16_f16 dense 16-bit peak 2.5 PF; the split issues 3 products x (208/201 K, 104/100 N "
+                           "padding) = 3.23 matrix FLOP per algorithmic FLOP, so frac <= 0.31 by construction; back-to-back "
+                           "MFMAs on real operand bits sustain 1.4-1.6 PF on this part at its 1,400 W limit (profiles/r02/README.md)",
+              "issued_per_algorithmic": 3.0 * (208.0 / 201.0) * (104.0 / 100.0)},
+    "f16x3lm": {"peak": 2500.0, "kernel": "lstm16::bilstm_f16x3_kernel", "dtype": "f16x3",
+                "label": "split-f16 MFMA, layer-major kernel of round 1 (h sequence of a layer through a global scratch)",
+                "peak_note": "v_mfma_f32_16x16x32_f16; 3 products x 576/507 K padding = 3.41 matrix FLOP per algorithmic FLOP",
+                "issued_per_algorithmic": 3.0 * 576.0 / 507.0},
     "f32": {"peak": 157.3, "kernel": "lstm32::bilstm_f32_kernel", "dtype": "f32", "label": "fp32 MFMA",
             "peak_note": "v_mfma_f32_16x16x4_f32 dense fp32, 157.3 TF"},
 }
@@ -99,7 +104,7 @@ def cpu_baseline(weights, x_sample_src):
             "single_thread": {"value": one, "cores": 1, "sample": "%d windows in %.1f s" % (n_one, dt_one)}}
 
 
-KERNEL_SOURCES = {"f16x3": ["lstm_f16.hip.inc"], "f32": ["lstm_f32.hip.inc"]}
+KERNEL_SOURCES = {"f16x3": ["lstm_f16s.hip.inc"], "f16x3lm": ["lstm_f16.hip.inc"], "f32": ["lstm_f32.hip.inc"]}
 
 
 def kernel_source_sha(precision):
@@ -162,7 +167,7 @@ def extras(m, _lib, model, precision, x_dev0, x_host0, prob_dev, cls_dev, reps=4
     time from HIP events) and the PCIe-inclusive rate when the boundary is handed pageable host buffers."""
     out = {}
     m.set_option(_lib.DM_OPT_ASYNC, 0)
-    other = "f32" if precision == "f16x3" else "f16x3"
+    other = "f32" if precision.startswith("f16x3") else "f16x3"
     m.set_precision(other)
     m.predict_windows(x_dev0, prob=prob_dev, cls=cls_dev)
     m.sync()

@@ -18,9 +18,6 @@
 #include "lstm_f32.hip.inc"
 #include "lstm_f16.hip.inc"
 #include "lstm_f16s.hip.inc"
-#ifdef DM_EXPERIMENT_F16T   // tools/experiments/f16t: tile-major split-f16 kernel (parity-clean, same speed: profiles/r02/README.md); dev builds only
-#include "lstm_f16t.hip.inc"
-#endif
 
 #ifdef DM_TRACE2
 #define DM16_TRACE2_LDS 2048
@@ -28,8 +25,6 @@
 #define DM16_TRACE2_LDS 0
 #endif
 
-#define DM_PREC_F16X3S 3   /* step-major tile-major split-f16 kernel (lstm_f16s.hip.inc) */
-#define DM_PREC_F16X3T 2   /* DM_EXPERIMENT_F16T builds: the tile-major kernel of tools/experiments/f16t */
 
 namespace {
 
@@ -213,7 +208,7 @@ Packed16 pack_weights_f16(const float* flat) {
     return P;
 }
 
-// tile-major split-f16 packing (lstm_f16s.hip.inc; tools/experiments/f16t uses the same): [dir][layer][tile][k16-step][hi|lo][lane][8 x f16].
+// tile-major split-f16 packing (lstm_f16s.hip.inc): [dir][layer][tile][k16-step][hi|lo][lane][8 x f16].
 // A-operand lane l of record (tile T, k16-step t): gate row m = l % 32 -> unit 8T + m / 4, gate m % 4;
 // k = (half = l / 32, j = 0..7) -> K slot of the B operand the kernel builds in registers:
 //   t < 6 : own unit 8 (2t + j/4) + 2 (j%4) + half
@@ -388,9 +383,8 @@ struct dm_model {
     float* d_wpack = nullptr;
     float* d_bpack = nullptr;
     float* d_hpack = nullptr;
-    unsigned char* d_wpack16 = nullptr;   // split-f16 weights (DM_PREC_F16X3)
-    unsigned char* d_wpack16s = nullptr;  // tile-major split-f16 weights (lstm_f16s.hip.inc)
-    unsigned char* d_wpack16t = nullptr;  // split-f16 weights of the experimental tile-major kernel (DM_EXPERIMENT_F16T builds)
+    unsigned char* d_wpack16 = nullptr;   // split-f16 weights in the layer-major kernel's layout (DM_PREC_F16X3_LM)
+    unsigned char* d_wpack16s = nullptr;  // split-f16 weights in the tile-major layout (DM_PREC_F16X3)
     float* d_wout = nullptr;              // head W[200][2] fp32 (DM_PREC_F16X3)
     float* d_scratch = nullptr;
     unsigned long long* d_dbg = nullptr;  // DM_TIMING builds only
@@ -411,6 +405,7 @@ struct dm_model {
     bool profile = false;
     bool async = false;                   // DM_OPT_ASYNC: device-resident calls return after enqueue
     int precision = DM_PREC_F16X3;        // default: fastest mode that meets the 1e-4 probability tolerance
+    float f16_max_abs = 0.0f;             // largest |packed weight| (x exponent scale)
     bool f16_ok = true;                   // every packed weight is a finite f16 (checked at create; else the default is DM_PREC_F32)
     int len_shift = 0;                    // DM_INFO_F16_LENGTH_SHIFT
     int* range_flag = nullptr;            // host-mapped word the f16x3 kernel sets on an input it cannot represent
@@ -474,26 +469,22 @@ int ensure_plogit(dm_model* m, int64_t ntiles) {
     return DM_OK;
 }
 
-int ensure_f16(dm_model* m) {
-    if (m->d_wpack16) return DM_OK;
-    Packed16 P = pack_weights_f16(m->host_weights.data());
-    if (!P.finite || P.max_abs > 65504.0f)
+// what both split-f16 kernels need: weights that fit an f16 after the exponent-scale fold (checked once in model_init),
+// the fp32 head weights
+int ensure_f16_common(dm_model* m) {
+    if (!m->f16_ok)
         return fail(DM_EINVAL, "DM_PREC_F16X3: a packed weight (|w| x exponent scale = %g) is outside the f16 range; use DM_PREC_F32",
-                    double(P.max_abs));
-    m->len_shift = P.len_shift;
-    HIP_TRY(hipMalloc(&m->d_wpack16, P.w.size()));
-    HIP_TRY(hipMemcpy(m->d_wpack16, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
+                    double(m->f16_max_abs));
+    if (m->d_wout) return DM_OK;
     const float* wout = m->host_weights.data() + (DM_WEIGHT_FLOATS - 402);
     HIP_TRY(hipMalloc(&m->d_wout, 400 * sizeof(float)));
     HIP_TRY(hipMemcpy(m->d_wout, wout, 400 * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16::bilstm_f16x3_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16::LDS_BYTES) + DM16_TRACE2_LDS));
     return DM_OK;
 }
 
 int ensure_f16s(dm_model* m) {
     if (m->d_wpack16s) return DM_OK;
-    int rc = ensure_f16(m);          // representability check, head weights, len_shift
+    int rc = ensure_f16_common(m);
     if (rc) return rc;
     Packed16 P = pack_weights_tile(m->host_weights.data());
     HIP_TRY(hipMalloc(&m->d_wpack16s, P.w.size()));
@@ -503,20 +494,17 @@ int ensure_f16s(dm_model* m) {
     return DM_OK;
 }
 
-#ifdef DM_EXPERIMENT_F16T
-int ensure_f16t(dm_model* m) {
-    if (m->d_wpack16t) return DM_OK;
-    int rc = ensure_f16(m);          // representability check, head weights, len_shift
+int ensure_f16lm(dm_model* m) {
+    if (m->d_wpack16) return DM_OK;
+    int rc = ensure_f16_common(m);
     if (rc) return rc;
-    Packed16 P = pack_weights_tile(m->host_weights.data());
-    HIP_TRY(hipMalloc(&m->d_wpack16t, P.w.size()));
-    HIP_TRY(hipMemcpy(m->d_wpack16t, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16t::bilstm_f16t_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16t::LDS_BYTES)));
+    Packed16 P = pack_weights_f16(m->host_weights.data());
+    HIP_TRY(hipMalloc(&m->d_wpack16, P.w.size()));
+    HIP_TRY(hipMemcpy(m->d_wpack16, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16::bilstm_f16x3_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16::LDS_BYTES) + DM16_TRACE2_LDS));
     return DM_OK;
 }
-
-#endif
 
 // launch on device-resident buffers
 int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, float* d_prob, uint8_t* d_cls) {
@@ -539,7 +527,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         ++m->events_used;
         HIP_TRY(hipEventRecord(e0, m->stream));
     }
-    if (m->precision == DM_PREC_F16X3S) {
+    if (m->precision == DM_PREC_F16X3) {
         using namespace lstm16s;
         int rc = ensure_f16s(m);
         if (rc) return rc;
@@ -563,37 +551,9 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         hipLaunchKernelGGL(lstm16::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
                            npad, m->bout[0], m->bout[1], d_prob, d_cls);
     } else
-#ifdef DM_EXPERIMENT_F16T
-    if (m->precision == DM_PREC_F16X3T) {
-        using namespace lstm16t;
-        int rc = ensure_f16t(m);
-        if (rc) return rc;
-        Params p;
-        p.wpack = m->d_wpack16t;
-        p.hpack = m->d_wout;
-        p.bout0 = m->bout[0];
-        p.bout1 = m->bout[1];
-        p.x = d_x;
-        p.xstride = xstride;
-        p.n = n;
-        p.scratch = reinterpret_cast<unsigned char*>(m->d_scratch);
-        p.ntiles = int((n + TILE_M - 1) / TILE_M);
-        int rcp = ensure_plogit(m, p.ntiles);
-        if (rcp) return rcp;
-        p.plogit = m->d_plogit;
-        p.len_scale = std::ldexp(1.0f, -m->len_shift);
-        p.range_flag = m->d_range_flag;
-        p.dbg = m->d_dbg;
-        const int grid = std::min(2 * p.ntiles, m->grid_cap);
-        hipLaunchKernelGGL(bilstm_f16t_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
-        const long long npad = (long long)p.ntiles * TILE_M;
-        hipLaunchKernelGGL(lstm16::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
-                           npad, m->bout[0], m->bout[1], d_prob, d_cls);
-    } else
-#endif
-    if (m->precision == DM_PREC_F16X3) {
+    if (m->precision == DM_PREC_F16X3_LM) {
         using namespace lstm16;
-        int rc = ensure_f16(m);
+        int rc = ensure_f16lm(m);
         if (rc) return rc;
         Params p;
         p.wpack = m->d_wpack16;
@@ -777,12 +737,9 @@ int model_init(dm_model* m, const float* weights) {
     HIP_TRY(hipMemcpy(m->d_bpack, P.b.data(), P.b.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_hpack, P.h.data(), P.h.size() * sizeof(float), hipMemcpyHostToDevice));
     size_t scratch_bytes = size_t(m->grid_cap) * std::max(SCRATCH_FLOATS_PER_WG * sizeof(float), lstm16::SCRATCH_BYTES_PER_WG);
-#ifdef DM_EXPERIMENT_F16T
-    scratch_bytes = std::max(scratch_bytes, size_t(m->grid_cap) * lstm16t::SCRATCH_BYTES_PER_WG);
-#endif
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
     HIP_TRY(hipMemset(m->d_scratch, 0, scratch_bytes));
-#if defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2) || defined(DM16T_TRACE)
+#if defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2)
     HIP_TRY(hipMalloc(&m->d_dbg, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(m->d_dbg, 0, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long)));
 #endif
@@ -792,8 +749,9 @@ int model_init(dm_model* m, const float* weights) {
     *m->range_flag = 0;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_range_flag), m->range_flag, 0));
     {   // trained kernels far outside the usual range cannot be split into f16 halves: such a model runs the fp32 kernel
-        Packed16 P16 = pack_weights_f16(weights);
+        Packed16 P16 = pack_weights_tile(weights);
         m->f16_ok = P16.finite && P16.max_abs <= 65504.0f;
+        m->f16_max_abs = P16.finite ? P16.max_abs : INFINITY;
         m->len_shift = P16.len_shift;
         m->precision = m->f16_ok ? DM_PREC_F16X3 : DM_PREC_F32;
     }
@@ -864,7 +822,6 @@ void dm_model_destroy(dm_model* m) {
     (void)hipFree(m->d_scratch);
     (void)hipFree(m->d_wpack16);
     (void)hipFree(m->d_wpack16s);
-    (void)hipFree(m->d_wpack16t);
     (void)hipFree(m->d_wout);
     (void)hipFree(m->d_dbg);
     (void)hipFree(m->d_plogit);
@@ -888,17 +845,7 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
             m->async = value != 0;
             return DM_OK;
         case DM_OPT_PRECISION:
-            if (value == DM_PREC_F16X3S && m->f16_ok) {
-                m->precision = int(value);
-                return DM_OK;
-            }
-#ifdef DM_EXPERIMENT_F16T
-            if (value == DM_PREC_F16X3T && m->f16_ok) {
-                m->precision = int(value);
-                return DM_OK;
-            }
-#endif
-            if (value != DM_PREC_F32 && value != DM_PREC_F16X3) return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
+            if (value != DM_PREC_F32 && value != DM_PREC_F16X3 && value != DM_PREC_F16X3_LM) return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
             if (value != DM_PREC_F32 && !m->f16_ok)
                 return fail(DM_EINVAL, "DM_PREC_F16X3 refused: a packed weight of this model is outside the f16 range (|w| x 2.886 > 65504)");
             m->precision = int(value);

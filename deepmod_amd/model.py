@@ -90,7 +90,7 @@ def _ptr(a):
 class BiLSTMModel:
     """One dm_model on one GPU (one per process, like the reference's one TF session per process)."""
 
-    PRECISIONS = {"f32": _lib.DM_PREC_F32, "f16x3": _lib.DM_PREC_F16X3, "f16x3s": _lib.DM_PREC_F16X3S, "f16x3t": _lib.DM_PREC_F16X3T}
+    PRECISIONS = {"f32": _lib.DM_PREC_F32, "f16x3": _lib.DM_PREC_F16X3, "f16x3lm": _lib.DM_PREC_F16X3_LM}
 
     def __init__(self, tensors: Dict[str, np.ndarray], device: int = 0, precision: Optional[str] = None):
         self._lib = _lib.load()

@@ -60,6 +60,8 @@ extern "C" {
 #define DM_PREC_F32 0      /* fp32 MFMA (v_mfma_f32_16x16x4_f32): fp32 products, the TF graph's own arithmetic */
 #define DM_PREC_F16X3 1    /* split-f16 MFMA: every fp32 operand = hi + lo f16, 3 products per fp32 product, fp32
                               accumulation; max |dp| vs the oracle 1e-6 .. 2e-6 (tolerance of the path: 1e-4), ~3x faster.
+                              Step-major kernel (csrc/lstm_f16s.hip.inc): weights and feature rows in, logits out, the
+                              state of the three layers never leaves the chip.
                               Range contract (nothing is clamped silently):
                                 * weights: every kernel / bias value times its exponent scale (<= 2.886) must be a finite f16
                                   (|w| <~ 22,700).  A model that violates this is created with DM_PREC_F32 as its default and
@@ -69,6 +71,9 @@ extern "C" {
                                   beyond 65504 it is fed as x * 2^-k against a weight row stored x 2^k (exact rescale).
                                   An input outside these bounds (or NaN) makes the call fail with DM_ERANGE - synchronous
                                   calls on return, DM_OPT_ASYNC calls at the next dm_model_sync. */
+#define DM_PREC_F16X3_LM 2 /* the same arithmetic and range contract in the layer-major kernel of round 1
+                              (csrc/lstm_f16.hip.inc: the h sequence of a layer goes through a per-workgroup global scratch);
+                              ~10 % slower, kept selectable as the second implementation the default is measured against. */
 /* dm_model_get_info keys */
 #define DM_INFO_PRECISION 1          /* DM_PREC_* in effect */
 #define DM_INFO_F16_REPRESENTABLE 2  /* 1 if the weights fit DM_PREC_F16X3 */

@@ -26,12 +26,12 @@ def _check(prob, cls, ref_prob, ref_cls):
     return err
 
 
-@pytest.fixture(scope="module", params=["f32", "f16x3"])
+@pytest.fixture(scope="module", params=["f32", "f16x3", "f16x3lm"])
 def models(gpu_device, request):
     """Every parity test runs for both precision modes of the library: exact-fp32 MFMA and the split-f16
     (3 products per fp32 product) MFMA path.  Same tolerance for both."""
     from deepmod_amd import _lib
-    prec = {"f32": _lib.DM_PREC_F32, "f16x3": _lib.DM_PREC_F16X3, "f16x3s": _lib.DM_PREC_F16X3S, "f16x3t": _lib.DM_PREC_F16X3T}[request.param]
+    prec = {"f32": _lib.DM_PREC_F32, "f16x3": _lib.DM_PREC_F16X3, "f16x3lm": _lib.DM_PREC_F16X3_LM}[request.param]
     cache = {}
 
     def get(seed, scale):

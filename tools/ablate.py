@@ -3,6 +3,9 @@ construction) and time them on the GPU box.
 
     python tools/ablate.py build            # here (cross-compile)
     python tools/ablate.py run              # on the GPU box (via gpurun)
+
+DM_ABL_PREC picks the kernel the variants are timed on: 0 fp32 (lstm_f32.hip.inc, DM_ABL_* macros), 1 split-f16 step-major
+(lstm_f16s.hip.inc, DM16S_* macros, variants s_*), 2 split-f16 layer-major (lstm_f16.hip.inc, DM16_* macros).
 """
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,6 +27,12 @@ VARIANTS = {
     "prod1": ["-DDM16_ABL_1PROD"], "noseq16": ["-DDM16_ABL_NOSEQ"],
     "floor16": ["-DDM16_ABL_1PROD", "-DDM16_ABL_NOCELL", "-DDM16_ABL_NOSEQ", "-DDM16_ABL_NODMA", "-DDM16_ABL_NOBAR", "-DDM16_ABL_NOLDSB", "-DDM16_ABL_NOLDSB_NONZERO"],
     "prod2": ["-DDM16_ABL_2PROD"], "nocell16": ["-DDM16_ABL_NOCELL"], "prod2_nocell": ["-DDM16_ABL_2PROD", "-DDM16_ABL_NOCELL"],
+    # lstm_f16s.hip.inc (DM_ABL_PREC=1)
+    "s_nocell": ["-DDM16S_ABL_NOCELL"], "s_nodma": ["-DDM16S_ABL_NODMA"], "s_nobar": ["-DDM16S_ABL_NOBAR"], "s_prod2": ["-DDM16S_ABL_2PROD"],
+    "s_noldsa": ["-DDM16S_ABL_NOLDSA"], "s_nobar_nodma": ["-DDM16S_ABL_NOBAR", "-DDM16S_ABL_NODMA"],
+    "s_floor": ["-DDM16S_ABL_NOCELL", "-DDM16S_ABL_NODMA", "-DDM16S_ABL_NOBAR", "-DDM16S_ABL_NOLDSA"],
+    "s_mix": ["-DDM16S_MIX"], "s_parts": ["-DDM16S_PARTS"],
+    "s_nocell_noldsa": ["-DDM16S_ABL_NOCELL", "-DDM16S_ABL_NOLDSA"],
     "trace": ["-DDM_TRACE"],                                   # f16x3 kernel: per-wave timeline of one stage
     "w4": ["-DDM16_WAVES=4", "-DDM16_MT=2"],                   # f16x3 kernel: 4 waves x 2 M-tiles (one wave per SIMD)
     "w4timing": ["-DDM16_WAVES=4", "-DDM16_MT=2", "-DDM_TIMING"],

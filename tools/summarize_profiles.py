@@ -22,6 +22,6 @@ for d in sorted(glob.glob(src + "/pmc_*")):
 out["windows_per_launch"] = 65536
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (kernel_source_sha: bench.py marks this summary stale once the kernel sources change)
-out["kernel_src_sha"] = bench.kernel_source_sha("f32" if tag.endswith("f32") else "f16x3")
+out["kernel_src_sha"] = bench.kernel_source_sha(tag.split("_", 1)[1] if "_" in tag else "f16x3")
 json.dump(out, open(os.path.join(dest, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps({k: (v["mean_per_launch"] if isinstance(v, dict) else v) for k, v in out.items()}, indent=1))

@@ -31,7 +31,7 @@ VARIANTS = {
     "s_nocell": ["-DDM16S_ABL_NOCELL"], "s_nodma": ["-DDM16S_ABL_NODMA"], "s_nobar": ["-DDM16S_ABL_NOBAR"], "s_prod2": ["-DDM16S_ABL_2PROD"],
     "s_noldsa": ["-DDM16S_ABL_NOLDSA"], "s_nobar_nodma": ["-DDM16S_ABL_NOBAR", "-DDM16S_ABL_NODMA"],
     "s_floor": ["-DDM16S_ABL_NOCELL", "-DDM16S_ABL_NODMA", "-DDM16S_ABL_NOBAR", "-DDM16S_ABL_NOLDSA"],
-    "s_mix": ["-DDM16S_MIX"], "s_parts": ["-DDM16S_PARTS"],
+    "s_mix": ["-DDM16S_MIX"], "s_pre0": ["-DDM16S_PRE=0"], "s_pre1": ["-DDM16S_PRE=1"], "s_pre3": ["-DDM16S_PRE=3"], "s_pre4": ["-DDM16S_PRE=4"],
     "s_nocell_noldsa": ["-DDM16S_ABL_NOCELL", "-DDM16S_ABL_NOLDSA"],
     "trace": ["-DDM_TRACE"],                                   # f16x3 kernel: per-wave timeline of one stage
     "w4": ["-DDM16_WAVES=4", "-DDM16_MT=2"],                   # f16x3 kernel: 4 waves x 2 M-tiles (one wave per SIMD)

@@ -33,10 +33,12 @@ PRECISIONS = {
     "f16x3": {"peak": 2500.0, "kernel": "lstm16s::bilstm_f16s_kernel", "dtype": "f16x3",
               "label": "split-f16 MFMA (hi+lo f16 operands, 3 products per fp32 product, fp32 accumulate), step-major: "
                        "the state of all three layers stays on the chip",
-              "peak_note": "v_mfma_f32_32x32x16_f16 dense 16-bit peak 2.5 PF; the split issues 3 products x (208/201 K, 104/100 N "
-                           "padding) = 3.23 matrix FLOP per algorithmic FLOP, so frac <= 0.31 by construction; back-to-back "
-                           "MFMAs on real operand bits sustain 1.4-1.6 PF on this part at its 1,400 W limit (profiles/r02/README.md)",
-              "issued_per_algorithmic": 3.0 * (208.0 / 201.0) * (104.0 / 100.0)},
+              "peak_note": "v_mfma_f32_32x32x16_f16 dense 16-bit peak 2.5 PF; the kernel issues 345 k16-steps x 13 tiles x 3 products of "
+                           "32x32x16 per 32 windows and direction = 27.55 MFLOP per window = 3.09 matrix FLOP per algorithmic FLOP "
+                           "(3 products, K 208/201 and N 104/100 padding, minus the zero-state k16-steps of step 0), so frac <= 0.32 "
+                           "by construction; back-to-back MFMAs on real operand bits sustain 1.4-1.6 PF on this part at its "
+                           "1,400 W limit (profiles/r02/README.md)",
+              "issued_per_algorithmic": 345 * 13 * 3 * 4 * 32768 * 2 / 128.0 / FLOP_PER_WINDOW},
     "f16x3lm": {"peak": 2500.0, "kernel": "lstm16::bilstm_f16x3_kernel", "dtype": "f16x3",
                 "label": "split-f16 MFMA, layer-major kernel of round 1 (h sequence of a layer through a global scratch)",
                 "peak_note": "v_mfma_f32_16x16x32_f16; 3 products x 576/507 K padding = 3.41 matrix FLOP per algorithmic FLOP",
@@ -154,10 +156,10 @@ def power_evidence(precision):
         ck = re.search(r"sclk MHz while busy: median (\d+)", txt)
         out = {"source": os.path.relpath(path, ROOT), "socket_power_w_busy_median": float(pw.group(1)) if pw else None,
                "socket_power_cap_w": 1400.0, "sclk_mhz_busy_median": int(ck.group(1)) if ck else None, "sclk_mhz_max": 2400}
-        if precision == "f16x3":
-            out["same_mix_microbenchmark_tflops"] = 1200.0
-            out["note"] = ("the kernel runs at the package power limit; back-to-back f16 MFMAs on real operand bits sustain 1,400-1,650 TFLOP/s "
-                           "on this part and 1,200 with this kernel's VALU / LDS filler mix (profiles/%s/ubench_mfma32_fill.txt)" % rnd)
+        if precision.startswith("f16x3"):
+            out["note"] = ("the split-f16 kernels run at or near the package power limit with the shader clock held at ~2.0-2.2 GHz; "
+                           "back-to-back f16 MFMAs on real operand bits sustain 1,400-1,650 TFLOP/s on this part (clock 1.36-1.49 GHz) "
+                           "and 1,200 with a VALU / LDS filler mix like this kernel's (profiles/%s/ubench_mfma32_fill.txt)" % rnd)
         return out
     return None
 

@@ -29,9 +29,9 @@ VARIANTS = {
     "prod2": ["-DDM16_ABL_2PROD"], "nocell16": ["-DDM16_ABL_NOCELL"], "prod2_nocell": ["-DDM16_ABL_2PROD", "-DDM16_ABL_NOCELL"],
     # lstm_f16s.hip.inc (DM_ABL_PREC=1)
     "s_nocell": ["-DDM16S_ABL_NOCELL"], "s_nodma": ["-DDM16S_ABL_NODMA"], "s_nobar": ["-DDM16S_ABL_NOBAR"], "s_prod2": ["-DDM16S_ABL_2PROD"],
-    "s_noldsa": ["-DDM16S_ABL_NOLDSA"], "s_nobar_nodma": ["-DDM16S_ABL_NOBAR", "-DDM16S_ABL_NODMA"],
+    "s_noldsa": ["-DDM16S_ABL_NOLDSA"], "s_b64": ["-DDM16S_ABL_B64"], "s_hionly": ["-DDM16S_ABL_LO_ONLY"], "s_nobar_nodma": ["-DDM16S_ABL_NOBAR", "-DDM16S_ABL_NODMA"],
     "s_floor": ["-DDM16S_ABL_NOCELL", "-DDM16S_ABL_NODMA", "-DDM16S_ABL_NOBAR", "-DDM16S_ABL_NOLDSA"],
-    "s_mix": ["-DDM16S_MIX"], "s_pre0": ["-DDM16S_PRE=0"], "s_pre1": ["-DDM16S_PRE=1"], "s_pre3": ["-DDM16S_PRE=3"], "s_pre4": ["-DDM16S_PRE=4"],
+    "s_ad2": ["-DDM16S_ADIST=2"], "s_ad4": ["-DDM16S_ADIST=4"], "s_ad5": ["-DDM16S_ADIST=5"], "s_ad6": ["-DDM16S_ADIST=6"], "s_pre0": ["-DDM16S_PRE=0"], "s_pre1": ["-DDM16S_PRE=1"], "s_pre3": ["-DDM16S_PRE=3"], "s_pre4": ["-DDM16S_PRE=4"],
     "s_nocell_noldsa": ["-DDM16S_ABL_NOCELL", "-DDM16S_ABL_NOLDSA"],
     "trace": ["-DDM_TRACE"],                                   # f16x3 kernel: per-wave timeline of one stage
     "w4": ["-DDM16_WAVES=4", "-DDM16_MT=2"],                   # f16x3 kernel: 4 waves x 2 M-tiles (one wave per SIMD)
@@ -49,7 +49,7 @@ def build(names):
     src = os.path.join(ROOT, "deepmod_amd", "csrc", "deepmod_hip.hip")
     for name in names:
         out = os.path.join(ABL, "lib_%s.so" % name)
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", out, src,
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form", "-o", out, src,
                "-ldl"] + VARIANTS[name]
         subprocess.check_call(cmd, cwd=os.path.dirname(src))
         print("built", out)

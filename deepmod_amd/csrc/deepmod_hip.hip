@@ -411,6 +411,7 @@ struct dm_model {
     int* range_flag = nullptr;            // host-mapped word the f16x3 kernel sets on an input it cannot represent
     int* d_range_flag = nullptr;          // its device address
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    hipEvent_t marks[DM_MARKS] = {};     // dm_model_mark / dm_model_wait_mark
     size_t events_used = 0;
     double prof_ms = 0.0;
     int64_t prof_launches = 0, prof_windows = 0;
@@ -816,6 +817,8 @@ void dm_model_destroy(dm_model* m) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    for (hipEvent_t e : m->marks)
+        if (e) (void)hipEventDestroy(e);
     (void)hipFree(m->d_wpack);
     (void)hipFree(m->d_bpack);
     (void)hipFree(m->d_hpack);
@@ -952,6 +955,45 @@ int dm_model_h2d_async(dm_model* m, void* dst, const void* src, size_t bytes) {
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m->stream));
     return DM_OK;
+}
+
+void* dm_host_alloc(int device, size_t bytes) {
+    if (hipSetDevice(device) != hipSuccess) {
+        fail(DM_EDEVICE, "hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(DM_ENOMEM, "hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+int dm_host_free(int device, void* p) {
+    if (!p) return DM_OK;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipHostFree(p));
+    return DM_OK;
+}
+
+int dm_model_mark(dm_model* m, int i) {
+    if (!m) return fail(DM_EINVAL, "null model");
+    if (i < 0 || i >= DM_MARKS) return fail(DM_EINVAL, "marker %d outside [0, %d)", i, DM_MARKS);
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->marks[i]) HIP_TRY(hipEventCreateWithFlags(&m->marks[i], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(m->marks[i], m->stream));
+    return DM_OK;
+}
+
+int dm_model_wait_mark(dm_model* m, int i) {
+    if (!m) return fail(DM_EINVAL, "null model");
+    if (i < 0 || i >= DM_MARKS) return fail(DM_EINVAL, "marker %d outside [0, %d)", i, DM_MARKS);
+    if (!m->marks[i]) return DM_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipEventSynchronize(m->marks[i]));
+    return check_range(m);
 }
 
 int dm_memcpy_d2h(int device, void* dst, const void* src, size_t bytes) {

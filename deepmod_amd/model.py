@@ -79,6 +79,32 @@ class DeviceArray:
             pass
 
 
+class PinnedArray:
+    """Page-locked host bytes (hipHostMalloc through the C ABI) with numpy views: staging memory uploads run from as DMA."""
+
+    def __init__(self, nbytes: int, device: int = 0):
+        self.device, self.nbytes = device, int(nbytes)
+        self.ptr = _lib.load().dm_host_alloc(device, max(self.nbytes, 1))
+        if not self.ptr:
+            raise _lib.DeepModHipError(_lib.last_error())
+        self._buf = (ctypes.c_char * max(self.nbytes, 1)).from_address(self.ptr)
+
+    def view(self, dtype, count: int, offset: int = 0) -> np.ndarray:
+        return np.frombuffer(self._buf, dtype, count, offset)
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self._buf = None
+            _lib.load().dm_host_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def _ptr(a):
     if a is None:
         return None
@@ -149,6 +175,14 @@ class BiLSTMModel:
     def upload_async(self, dst_ptr: int, arr: np.ndarray):
         """Host array -> device address, queued on the model's stream (keep `arr` alive until the next sync())."""
         _lib.check(self._lib.dm_model_h2d_async(self._h, dst_ptr, arr.ctypes.data, arr.nbytes))
+
+    def mark(self, i: int):
+        """Record marker i on the model's stream (after the launches queued so far)."""
+        _lib.check(self._lib.dm_model_mark(self._h, i))
+
+    def wait_mark(self, i: int):
+        """Block until marker i has passed (at once if never recorded)."""
+        _lib.check(self._lib.dm_model_wait_mark(self._h, i))
 
     def predict_rows_device(self, rows_ptr: int, m_rows: int, first: int, count: int, cls_ptr: int, prob_ptr=None):
         """dm_predict_read on raw device addresses (staging buffers of the streaming worker)."""

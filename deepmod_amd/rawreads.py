@@ -94,6 +94,9 @@ def get_Event_Signals(moptions, sp_options, raw_files, normalizer=None):
     f5data = {}
     if "Error" not in sp_options:
         sp_options["Error"] = defaultdict(list)
+    # events of every read of every container of the batch first (host), then ONE device round trip for their signal
+    # statistics (a feeder process shares the GPU with the classifier: few, larger launches)
+    pending = []
     for f5f in raw_files:
         try:
             reads = load_raw_container(f5f)
@@ -101,8 +104,6 @@ def get_Event_Signals(moptions, sp_options, raw_files, normalizer=None):
             sp_options["Error"]["Cannot open fast5 or other errors"].append(f5f)
             print("Cannot open fast5 or other errors: {}".format(f5f))
             continue
-        # events of every read of the container first (host), then ONE device round trip for their signal statistics
-        pending = []
         for rd in reads:
             sp_param = {'mfile_path': f5f, 'f5status': '', 'raw_signals': rd['raw'], 'events_data': rd['events_data'],
                         'read_id': rd['read_id'].replace(" ", ":::").replace("\t", "|||")}
@@ -112,17 +113,18 @@ def get_Event_Signals(moptions, sp_options, raw_files, normalizer=None):
                 sp_param['f5status'] = "Cannot open fast5 or other errors"
                 print("Cannot open fast5 or other errors: {} ({})".format(f5f, exc))
             pending.append(sp_param)
-        ok = [sp for sp in pending if sp['f5status'] == '']
-        for sp, exc in zip(ok, dm_signal.mnormalized_event_stats_batch(moptions, ok, normalizer) if ok else []):
-            if exc is not None:
-                sp['f5status'] = "Cannot open fast5 or other errors"
-                print("Cannot open fast5 or other errors: {} ({})".format(f5f, exc))
-        for sp_param in pending:
-            if sp_param['f5status'] == '':
-                if sp_param['read_id'] in f5data:
-                    print('Duplicate id', sp_param['read_id'], f5f)
-                f5data[sp_param['read_id']] = (sp_param['m_event_basecall'], sp_param['m_event'], None, f5f,
-                                               sp_param['left_right_skip'])
-            else:
-                sp_options["Error"][sp_param['f5status']].append(f5f)
+    ok = [sp for sp in pending if sp['f5status'] == '']
+    for sp, exc in zip(ok, dm_signal.mnormalized_event_stats_batch(moptions, ok, normalizer) if ok else []):
+        if exc is not None:
+            sp['f5status'] = "Cannot open fast5 or other errors"
+            print("Cannot open fast5 or other errors: {} ({})".format(sp['mfile_path'], exc))
+    for sp_param in pending:
+        f5f = sp_param['mfile_path']
+        if sp_param['f5status'] == '':
+            if sp_param['read_id'] in f5data:
+                print('Duplicate id', sp_param['read_id'], f5f)
+            f5data[sp_param['read_id']] = (sp_param['m_event_basecall'], sp_param['m_event'], None, f5f,
+                                           sp_param['left_right_skip'])
+        else:
+            sp_options["Error"][sp_param['f5status']].append(f5f)
     return f5data

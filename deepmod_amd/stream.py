@@ -38,7 +38,7 @@ HALF = 10          # windowsize // 2
 
 class Prepared:
     """One worker batch, ready for the device.  Rows of the reads are concatenated, reads grouped by (contig, strand)."""
-    __slots__ = ('rows', 'pos', 'flags', 'n_rows', 'groups', 'n_windows', 'n_reads', 'errors', 'contig_len', 'timing', 'files')
+    __slots__ = ('rows', 'pos', 'flags', 'n_rows', 'groups', 'n_windows', 'n_reads', 'errors', 'contig_len', 'timing', 'files', 'on_done')
 
     def __init__(self):
         self.rows = np.zeros((0, 7), np.float32)
@@ -52,6 +52,7 @@ class Prepared:
         self.contig_len: Dict[str, int] = {}
         self.timing: Dict[str, float] = defaultdict(float)
         self.files: List[str] = []
+        self.on_done = None          # called once the device has consumed the host arrays (a feeder slot goes back to its queue)
 
 
 def rows_from_packed(pk: Dict, base: str, src: str, out: Prepared) -> None:
@@ -135,8 +136,10 @@ def rows_from_reads(reads: Iterable[Dict], base: str, src: str, out: Prepared) -
     rows_from_packed(pk, base, src, out)
 
 
-def finish(out: Prepared) -> Prepared:
-    """Group the collected reads by (contig, strand) and build the contiguous host arrays of the batch."""
+def finish(out: Prepared, alloc=None) -> Prepared:
+    """Group the collected reads by (contig, strand) and build the contiguous host arrays of the batch.
+    alloc(n_rows, n_pos) -> (rows[n_rows, 7] f32, pos[n_pos] i64, flags[n_pos] u8) lets a feeder process build them directly in
+    shared memory."""
     pieces = out._pieces
     order = sorted(range(len(pieces)), key=lambda i: (pieces[i][0], pieces[i][1]))
     rows, pos, flags, xpos, xflags = [], [], [], [], []
@@ -159,7 +162,12 @@ def finish(out: Prepared) -> Prepared:
                 out.contig_len[c] = mx            # lower bound when no reference length is known
     if cur is not None:
         out.groups.append((cur[0], cur[1], cur[2], r, cur[3], x))
-    if rows:
+    if rows and alloc is not None:
+        out.rows, out.pos, out.flags = alloc(r, r + x)
+        np.concatenate(rows, out=out.rows, casting='same_kind')
+        np.concatenate(pos + xpos, out=out.pos, casting='same_kind')
+        np.concatenate(flags + xflags, out=out.flags, casting='same_kind')
+    elif rows:
         out.rows = np.ascontiguousarray(np.concatenate(rows), np.float32)
         out.pos = np.concatenate(pos + xpos)
         out.flags = np.concatenate(flags + xflags)
@@ -176,7 +184,7 @@ class _PreparedBuilder(Prepared):
         self._pieces = []
 
 
-def prepare_batch(moptions, files: List[str], make_normalizer=None) -> Prepared:
+def prepare_batch(moptions, files: List[str], make_normalizer=None, alloc=None) -> Prepared:
     """Host side of one worker batch (the reference's mDetect1 up to the call of mPredict1, myDetect.py:392-465, :488-715):
     raw containers go through signal normalisation, alignment records, dm_map_read and get_Feature; feature containers
     enter at the prediction step."""
@@ -221,17 +229,149 @@ def prepare_batch(moptions, files: List[str], make_normalizer=None) -> Prepared:
         rows_from_packed(pk, base, cf, out)
         t0 = time.perf_counter()
         out.timing['rows'] += t0 - t1
-    finish(out)
+    finish(out, alloc)
     out.timing['rows'] += time.perf_counter() - t0
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# feeder processes: the host side of a batch is numpy / zipfile / small C calls per read - Python threads serialise on the
+# interpreter lock (32 feeder threads prepared 1.5x what one does), so the CLI prepares batches in worker PROCESSES and
+# hands the three arrays over through a file in /dev/shm that the GPU process maps (and unlinks at once).
+# ---------------------------------------------------------------------------------------------
+_ALIGN = 256
+
+
+def _shm_layout(n_rows: int, n_pos: int):
+    o_pos = -(-n_rows * 28 // _ALIGN) * _ALIGN
+    o_flags = o_pos + -(-n_pos * 8 // _ALIGN) * _ALIGN
+    return o_pos, o_flags, o_flags + max(n_pos, 1)
+
+
+def _shm_views(buf, n_rows: int, n_pos: int):
+    o_pos, o_flags, _ = _shm_layout(n_rows, n_pos)
+    return (np.frombuffer(buf, np.float32, n_rows * 7, 0).reshape(n_rows, 7), np.frombuffer(buf, np.int64, n_pos, o_pos),
+            np.frombuffer(buf, np.uint8, n_pos, o_flags))
+
+
+def usable_cpus() -> int:
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
+def shm_dir_for(moptions) -> str:
+    root = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else moptions['outFolder']
+    return os.path.join(root, 'deepmod_amd_%d' % os.getpid())
+
+
+def feeder_process_main(moptions, work, ready, device: int, shm_dir: str, wid: int, free_slots=None, slot_bytes: int = 0):
+    """Body of one feeder process: file lists from `work` (a multiprocessing queue of (files, ...) items, filled before the
+    run starts; empty = done) -> prepare_batch -> arrays into shared memory -> a small description on `ready`.
+    Shared memory = one of the GPU process' page-locked slot files (`free_slots`: queue of slot numbers; the batch must fit
+    `slot_bytes`), else a file of its own that the GPU process maps and unlinks."""
+    import mmap
+    import traceback
+    norm = []
+
+    def normalizer():                      # created on first use: only batches with raw containers need the device
+        if not norm:
+            from . import signal as dmsignal
+            norm.append(dmsignal.SignalNormalizer(device))
+        return norm[0]
+
+    slot_maps = {}
+
+    def slot_map(i):
+        if i not in slot_maps:
+            fd = os.open(os.path.join(shm_dir, 'slot_%d' % i), os.O_RDWR)
+            try:
+                slot_maps[i] = mmap.mmap(fd, slot_bytes)
+            finally:
+                os.close(fd)
+        return slot_maps[i]
+
+    seq = 0
+    try:
+        while True:
+            try:
+                item = work.get(block=False)
+            except Exception:              # queue.Empty (also through a manager proxy): nothing left
+                break
+            files = item[0] if isinstance(item, tuple) else item
+            path = os.path.join(shm_dir, 'b%d_%d' % (wid, seq))
+            seq += 1
+            holder = {}
+
+            def alloc(n_rows, n_pos):
+                size = _shm_layout(n_rows, n_pos)[2]
+                if free_slots is not None and size <= slot_bytes:
+                    holder['slot'] = free_slots.get()                    # blocks while the device queue holds every slot
+                    return _shm_views(slot_map(holder['slot']), n_rows, n_pos)
+                fd = os.open(path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+                try:
+                    os.ftruncate(fd, size)
+                    holder['mm'] = mmap.mmap(fd, size)
+                finally:
+                    os.close(fd)
+                return _shm_views(holder['mm'], n_rows, n_pos)
+
+            pb = prepare_batch(moptions, files, normalizer, alloc)
+            meta = {'path': path if 'mm' in holder else None, 'slot': holder.get('slot'), 'n_rows': pb.n_rows, 'n_pos': len(pb.pos),
+                    'groups': pb.groups, 'n_windows': pb.n_windows, 'n_reads': pb.n_reads, 'errors': {k: list(v) for k, v in pb.errors.items()},
+                    'contig_len': dict(pb.contig_len), 'timing': dict(pb.timing), 'files': list(pb.files)}
+            pb.rows = pb.pos = pb.flags = None          # drop the views before a mapping goes away
+            if 'mm' in holder:
+                holder['mm'].close()
+            ready.put(meta)
+    except BaseException:
+        ready.put({'failed': traceback.format_exc()})
+    finally:
+        ready.put(None)
+
+
+def prepared_from_shm(meta, slot_buffer=None) -> Prepared:
+    """The GPU process' view of a batch a feeder process prepared: in one of its page-locked slots (slot_buffer(i) -> the
+    slot's mapping), or in a file of its own (unlinked as soon as it is mapped)."""
+    import mmap
+    pb = Prepared()
+    pb.n_rows, pb.groups, pb.n_windows, pb.n_reads = meta['n_rows'], [tuple(g) for g in meta['groups']], meta['n_windows'], meta['n_reads']
+    for k, v in meta['errors'].items():
+        pb.errors[k].extend(v)
+    pb.contig_len = dict(meta['contig_len'])
+    for k, v in meta['timing'].items():
+        pb.timing[k] += v
+    pb.files = meta['files']
+    if meta.get('slot') is not None:
+        pb.rows, pb.pos, pb.flags = _shm_views(slot_buffer(meta['slot']), meta['n_rows'], meta['n_pos'])
+    elif meta['path'] is not None:
+        fd = os.open(meta['path'], os.O_RDONLY)
+        try:
+            mm = mmap.mmap(fd, 0, prot=mmap.PROT_READ)
+        finally:
+            os.close(fd)
+            os.unlink(meta['path'])
+        pb.rows, pb.pos, pb.flags = _shm_views(mm, meta['n_rows'], meta['n_pos'])
+    return pb
 
 
 # ---------------------------------------------------------------------------------------------
 # device backend (C ABI) and the rank-local engine
 # ---------------------------------------------------------------------------------------------
 class HipBackend:
-    """The device side of the engine through libdeepmod_hip.so: one model, one in-order stream, growable staging
-    buffers, one PositionSummary per contig x strand."""
+    """The device side of the engine through libdeepmod_hip.so: one model, one in-order stream, NSET staging sets (page-locked
+    host memory + device buffers, grow-only), one PositionSummary per contig x strand.  Batch k is copied into set k % NSET
+    while the device works on the batches before it; a stream marker per set says when the set may be refilled."""
+    NSET = 3
 
     def __init__(self, moptions, device: int):
         from . import _lib, model as dm
@@ -244,18 +384,20 @@ class HipBackend:
         self.model = self.sess.model
         self.model.set_option(_lib.DM_OPT_ASYNC, 1)
         self._dm = dm
-        self._buf = {}            # name -> DeviceArray (grow-only)
-        self._inflight = deque()  # host batches whose uploads may still be in flight
+        self._sets = [{'host': None, 'dev': None} for _ in range(self.NSET)]
+        self._k = 0
+        self.timing = defaultdict(float)   # where submit() spends the GPU process' time
 
-    def _device_buffer(self, name, nbytes):
-        cur = self._buf.get(name)
-        if cur is None or cur.nbytes < nbytes:
-            if cur is not None:
-                self.model.sync()
-                cur.free()
-            cur = self._dm.DeviceArray((int(nbytes * 1.25) + 4096,), np.uint8, self.device)
-            self._buf[name] = cur
-        return cur
+    def _staging(self, st, nbytes):
+        """(pinned host block, device block) of one set, both at least nbytes (the set's marker has passed: nothing reads them)."""
+        if st['host'] is None or st['host'].nbytes < nbytes:
+            cap = int(nbytes * 1.25) + 4096
+            for blk in (st['host'], st['dev']):
+                if blk is not None:
+                    blk.free()
+            st['host'] = self._dm.PinnedArray(cap, self.device)
+            st['dev'] = self._dm.DeviceArray((cap,), np.uint8, self.device)
+        return st['host'], st['dev']
 
     def new_summary(self, length: int):
         from . import summary
@@ -264,39 +406,58 @@ class HipBackend:
         return s
 
     def submit(self, pb: Prepared, summaries) -> None:
-        """Queue one batch: upload, classify every row (windows assembled on the device), accumulate per group.
-        Returns after enqueue; the host arrays stay referenced until the stream has passed them."""
+        """Queue one batch: stage, upload, classify every row (windows assembled on the device), accumulate per group.
+        Returns after enqueue; the batch's own arrays are free again on return (pb.on_done is called)."""
         if pb.n_rows == 0:
+            if pb.on_done is not None:
+                pb.on_done()
+                pb.on_done = None
             return
         R, T = pb.n_rows, len(pb.pos)
-        d_rows = self._device_buffer('rows', R * 28)
-        d_pos = self._device_buffer('pos', T * 8)
-        d_flags = self._device_buffer('flags', T)
-        d_cls = self._device_buffer('cls', R)
-        self.model.upload_async(d_rows.ptr, pb.rows)
-        self.model.upload_async(d_pos.ptr, pb.pos)
-        self.model.upload_async(d_flags.ptr, pb.flags)
+        o_pos, o_flags, end = _shm_layout(R, T)
+        o_cls = -(-end // _ALIGN) * _ALIGN
+        t0 = time.perf_counter()
+        i = self._k % self.NSET
+        self._k += 1
+        self.model.wait_mark(i)                    # the launches that read this set (batch k - NSET) are done
+        t1 = time.perf_counter()
+        host, dev = self._staging(self._sets[i], o_cls + R)
+        np.copyto(host.view(np.float32, R * 7).reshape(R, 7), pb.rows, casting='same_kind')
+        np.copyto(host.view(np.int64, T, o_pos), pb.pos, casting='same_kind')
+        np.copyto(host.view(np.uint8, T, o_flags), pb.flags, casting='same_kind')
+        if pb.on_done is not None:                 # e.g. the feeder's shared-memory slot goes back to its queue
+            pb.on_done()
+            pb.on_done = None
+        t2 = time.perf_counter()
+        self._lib_check(self._lib.dm_model_h2d_async(self.model._h, dev.ptr, host.ptr, end))
+        d_rows, d_pos, d_flags, d_cls = dev.ptr, dev.ptr + o_pos, dev.ptr + o_flags, dev.ptr + o_cls
         # window centred on row r -> cls[r]; rows 0..9 and R-10..R-1 are padding of the first / last read
-        self.model.predict_rows_device(d_rows.ptr, R, HALF, R - 2 * HALF, d_cls.ptr + HALF)
+        self.model.predict_rows_device(d_rows, R, HALF, R - 2 * HALF, d_cls + HALF)
         for (c, s, lo, hi, xlo, xhi) in pb.groups:
             summ = summaries(c, s, pb.contig_len.get(c, 0))
-            summ.add_classified_device(d_pos.ptr + 8 * lo, d_flags.ptr + lo, d_cls.ptr + lo, hi - lo)
+            summ.add_classified_device(d_pos + 8 * lo, d_flags + lo, d_cls + lo, hi - lo)
             if xhi > xlo:
-                summ.add_device(d_pos.ptr + 8 * (R + xlo), d_flags.ptr + R + xlo, xhi - xlo)
-        self._inflight.append(pb)
-        if len(self._inflight) > 2:      # bound the host memory held for uploads: drain, then drop the oldest batches
-            self.model.sync()
-            self._inflight.clear()
+                summ.add_device(d_pos + 8 * (R + xlo), d_flags + R + xlo, xhi - xlo)
+        self.model.mark(i)
+        t3 = time.perf_counter()
+        self.timing['wait_device'] += t1 - t0
+        self.timing['stage'] += t2 - t1
+        self.timing['launch'] += t3 - t2
+
+    def _lib_check(self, rc):
+        from . import _lib
+        _lib.check(rc)
 
     def sync(self):
         self.model.sync()
-        self._inflight.clear()
 
     def close(self):
         self.sync()
-        for b in self._buf.values():
-            b.free()
-        self._buf = {}
+        for st in self._sets:
+            for blk in (st['host'], st['dev']):
+                if blk is not None:
+                    blk.free()
+            st['host'] = st['dev'] = None
         self.sess.close()
 
 
@@ -389,6 +550,87 @@ class StreamEngine:
         self.backend.sync()
         self.stats['drain'] += time.perf_counter() - t0
         self.stats['detect_wall'] += time.perf_counter() - t_start
+        for k, v in getattr(self.backend, 'timing', {}).items():
+            self.stats['submit_' + k] += v
+
+    def run_processes(self, work, n_procs: int, device: int, ctx=None):
+        """Same as run(), with the batches prepared by `n_procs` feeder processes that drain `work` (a multiprocessing queue
+        of (files, ...) items shared by all ranks and filled before the run starts)."""
+        import multiprocessing
+        import shutil
+        t_start = time.perf_counter()
+        ctx = ctx or multiprocessing.get_context('spawn')
+        shm_dir = shm_dir_for(self.mo)
+        os.makedirs(shm_dir, exist_ok=True)
+        ready = ctx.Queue(maxsize=max(4, 2 * n_procs))
+        # hand-over slots: files in shm_dir, mapped once by both sides, that the feeders fill and this process copies into its
+        # page-locked staging memory (an upload straight from a shared-memory mapping ran at 0.7 GB/s, and page-locking the
+        # mapping itself faulted the GPU).  A batch larger than a slot falls back to a file of its own.
+        import mmap
+        slot_bytes = int(self.mo.get('feeder_slot_mb', 128)) << 20
+        n_slots = n_procs + 4 if self.mo.get('feeder_slots', True) else 0
+        try:
+            st = os.statvfs(shm_dir)
+            n_slots = min(n_slots, int(0.5 * st.f_bavail * st.f_frsize) // slot_bytes)
+        except OSError:
+            n_slots = 0
+        slots, free_slots = {}, None
+        if n_slots >= 4:
+            free_slots = ctx.Queue()
+            for i in range(n_slots):
+                fd = os.open(os.path.join(shm_dir, 'slot_%d' % i), os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+                os.ftruncate(fd, slot_bytes)
+                os.close(fd)
+                free_slots.put(i)
+
+        def slot_buffer(i):                  # mapped on first use
+            if i not in slots:
+                fd = os.open(os.path.join(shm_dir, 'slot_%d' % i), os.O_RDWR)
+                try:
+                    slots[i] = mmap.mmap(fd, slot_bytes)
+                finally:
+                    os.close(fd)
+            return slots[i]
+
+        procs = [ctx.Process(target=feeder_process_main, args=(self.mo, work, ready, device, shm_dir, i, free_slots, slot_bytes), daemon=True)
+                 for i in range(n_procs)]
+        for pr in procs:
+            pr.start()
+        try:
+            done = 0
+            while done < n_procs:
+                t0 = time.perf_counter()
+                try:
+                    item = ready.get(timeout=5.0)
+                except queue.Empty:
+                    if not any(pr.is_alive() for pr in procs) and ready.empty():
+                        raise RuntimeError('feeder processes ended without finishing their batches (exit codes %s)'
+                                           % [pr.exitcode for pr in procs])
+                    self.stats['wait_feed'] += time.perf_counter() - t0
+                    continue
+                self.stats['wait_feed'] += time.perf_counter() - t0
+                if item is None:
+                    done += 1
+                elif 'failed' in item:
+                    raise RuntimeError('a feeder process failed:\n' + item['failed'])
+                else:
+                    pb = prepared_from_shm(item, slot_buffer)
+                    if item.get('slot') is not None:
+                        pb.on_done = (lambda i=item['slot']: free_slots.put(i))
+                        self.stats['slot_batches'] += 1
+                    self.consume(pb)
+            t0 = time.perf_counter()
+            self.backend.sync()
+            self.stats['drain'] += time.perf_counter() - t0
+        finally:
+            for pr in procs:
+                pr.join(timeout=10)
+                if pr.is_alive():
+                    pr.terminate()
+            shutil.rmtree(shm_dir, ignore_errors=True)
+        self.stats['detect_wall'] += time.perf_counter() - t_start
+        for k, v in getattr(self.backend, 'timing', {}).items():
+            self.stats['submit_' + k] += v
 
     def finalize(self, gather, reduce_fn, write: bool = True) -> Dict[Tuple[str, str], bytes]:
         """Merge over ranks and write the BED files on rank 0.
@@ -435,9 +677,10 @@ def _drain(q):
         yield item[0]
 
 
-def stream_rank_main(moptions, rank: int, world: int, device: int, work, result_q=None, feeders: int = 2):
+def stream_rank_main(moptions, rank: int, world: int, device: int, work, result_q=None, feeders: int = 2, feeder_procs: int = 0):
     """Body of one GPU process.  `work`: a shared queue of (files, subfolder, batchid) items drained by all ranks,
-    or a list of file lists (static shard).  Returns / posts {'errors', 'stats'}."""
+    or a list of file lists (static shard).  feeder_procs > 0 (queue only): batches are prepared by that many feeder
+    processes of this rank; otherwise by `feeders` threads.  Returns / posts {'errors', 'stats'}."""
     from . import comm as dmcomm, signal as dmsignal
     communicator = rdv = None
     if world > 1:       # collectively, before any work: a rank that cannot join fails the run at once, not after its share of the reads
@@ -448,8 +691,11 @@ def stream_rank_main(moptions, rank: int, world: int, device: int, work, result_
     if moptions.get('Ref') and os.path.isfile(moptions['Ref']):
         from . import readmap
         eng.set_reference_lengths({c: len(s) for c, s in readmap.read_fasta(moptions['Ref']).items()})
-    batches = _drain(work) if hasattr(work, 'get') else iter(work)
-    eng.run(batches, feeders=feeders, make_normalizer=lambda: dmsignal.SignalNormalizer(device))
+    if feeder_procs > 0 and hasattr(work, 'get'):
+        eng.run_processes(work, feeder_procs, device)
+    else:
+        batches = _drain(work) if hasattr(work, 'get') else iter(work)
+        eng.run(batches, feeders=feeders, make_normalizer=lambda: dmsignal.SignalNormalizer(device))
     if communicator is not None:
         gather = lambda obj: rdv.all_gather_json('summary_keys', obj)
         reduce_fn = lambda s: s.reduce(communicator, 0)

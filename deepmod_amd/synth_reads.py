@@ -153,23 +153,26 @@ def synthetic_raw_read(rng, genome: str, chrom: str, read_id: str, min_len=400, 
 
 
 def write_synthetic_raw_run(out_dir: str, n_reads: int = 40, reads_per_file: int = 5, genome_len: int = 30000, seed: int = 1,
-                            chrom: str = 'NC_000913.3', **read_kw):
-    """Raw containers + side-car SAM files + genome FASTA.  -> (container paths, fasta path)"""
+                            chrom: str = 'NC_000913.3', part: int = 0, **read_kw):
+    """Raw containers + side-car SAM files + genome FASTA.  -> (container paths, fasta path).
+    `part` > 0 writes another slice of the same run (same genome, its own reads and file names; the FASTA is part 0's),
+    so that a large run can be generated by several processes."""
     from . import rawreads
     os.makedirs(out_dir, exist_ok=True)
     genome = synthetic_genome(genome_len, seed)
     fasta = os.path.join(out_dir, 'genome.fa')
-    with open(fasta, 'w') as fh:
-        fh.write('>%s synthetic\n' % chrom)
-        for i in range(0, len(genome), 60):
-            fh.write(genome[i:i + 60].lower() if (i // 60) % 7 == 3 else genome[i:i + 60])   # soft-masked stretches: upper-cased on load
-            fh.write('\n')
-    rng = np.random.default_rng(seed + 11)
+    if part == 0:
+        with open(fasta, 'w') as fh:
+            fh.write('>%s synthetic\n' % chrom)
+            for i in range(0, len(genome), 60):
+                fh.write(genome[i:i + 60].lower() if (i // 60) % 7 == 3 else genome[i:i + 60])   # soft-masked stretches: upper-cased on load
+                fh.write('\n')
+    rng = np.random.default_rng(seed + 11 + 1000003 * part)
     files, batch = [], []
     for i in range(n_reads):
-        batch.append(synthetic_raw_read(rng, genome, chrom, 'rawread_%05d' % i, **read_kw))
+        batch.append(synthetic_raw_read(rng, genome, chrom, 'rawread_%05d' % i if part == 0 else 'rawread_p%d_%05d' % (part, i), **read_kw))
         if len(batch) == reads_per_file or i == n_reads - 1:
-            stem = os.path.join(out_dir, 'raw_%04d' % len(files))
+            stem = os.path.join(out_dir, 'raw_%04d' % len(files) if part == 0 else 'raw_p%d_%04d' % (part, len(files)))
             rawreads.save_raw_container(stem + rawreads.RAW_SUFFIX, batch)
             with open(stem + '.sam', 'w') as fh:
                 fh.write('@SQ\tSN:%s\tLN:%d\n' % (chrom, len(genome)))

@@ -133,6 +133,16 @@ int dm_memcpy_d2h(int device, void* dst, const void* src, size_t bytes);
 /* host -> device copy queued on the model's stream (ordered with its launches; with DM_OPT_ASYNC a worker refills its
  * staging buffers without waiting for the device).  src must stay valid until the next dm_model_sync. */
 int dm_model_h2d_async(dm_model* m, void* dst, const void* src, size_t bytes);
+/* Page-locked host staging memory (hipHostMalloc) and stream markers for a pipelined worker: batch k is copied into staging
+ * set k % N while the device still works on batch k - 1; dm_model_mark(m, i) records a marker on the model's stream after the
+ * launches that read set i, dm_model_wait_mark(m, i) blocks the host until that marker has passed (at once if it was never
+ * recorded; a DM_ERANGE of the launches before the marker is reported here, as by dm_model_sync).  i in [0, DM_MARKS).  No reference counterpart: the reference feeds numpy arrays to session.run
+ * (myDetect.py:796-822). */
+#define DM_MARKS 8
+void* dm_host_alloc(int device, size_t bytes);
+int dm_host_free(int device, void* p);
+int dm_model_mark(dm_model* m, int i);
+int dm_model_wait_mark(dm_model* m, int i);
 
 /* ------------------------------------------------------------------ per-position summary -- */
 /*

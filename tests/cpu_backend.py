@@ -39,6 +39,14 @@ class OracleBackend:
         return CpuSummary(length)
 
     def submit(self, pb, summaries):
+        try:
+            self._submit(pb, summaries)
+        finally:
+            if pb.on_done is not None:          # the backend's contract: the batch's own arrays are free on return
+                pb.on_done()
+                pb.on_done = None
+
+    def _submit(self, pb, summaries):
         if pb.n_rows == 0:
             return
         R = pb.n_rows

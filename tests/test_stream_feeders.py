@@ -1,0 +1,89 @@
+"""CPU: feeder processes of the streaming detect (deepmod_amd/stream.py: feeder_process_main / prepared_from_shm /
+StreamEngine.run_processes).  A batch prepared in a worker process and handed over through a shared-memory file must be the
+batch prepare_batch() builds in-process, and the engine fed by processes must produce the BED bytes of the engine fed by
+threads (device calls replaced by the oracle stand-in of tests/cpu_backend.py, as in test_stream_gloo.py)."""
+import multiprocessing
+import os
+import queue
+
+import numpy as np
+
+from deepmod_amd import stream, synth, synth_reads
+from cpu_backend import OracleBackend
+
+
+def _files(tmp_path):
+    return synth_reads.write_synthetic_run(str(tmp_path / 'in'), n_reads=9, reads_per_file=2, genome_len=6000, seed=3, chrom='chrA',
+                                           min_len=120, max_len=400)
+
+
+def test_batch_through_shared_memory_equals_in_process_batch(tmp_path):
+    files = _files(tmp_path)
+    mo = {'Base': 'C', 'outFolder': str(tmp_path), 'fnum': 7, 'hidden': 100, 'windowsize': 21}
+    work, ready = queue.Queue(), queue.Queue()
+    work.put((files[:3], 0, 0))
+    work.put((files[3:], 0, 1))
+    shm = str(tmp_path / 'shm')
+    os.makedirs(shm)
+    stream.feeder_process_main(mo, work, ready, 0, shm, 0)          # the process body, run here
+    metas = []
+    while True:
+        m = ready.get()
+        if m is None:
+            break
+        assert 'failed' not in m, m
+        metas.append(m)
+    assert len(metas) == 2
+    for m, fl in zip(metas, (files[:3], files[3:])):
+        got = stream.prepared_from_shm(m)
+        assert not os.path.exists(m['path'])                         # unlinked as soon as it is mapped
+        ref = stream.prepare_batch(mo, fl)
+        assert got.n_rows == ref.n_rows and got.n_reads == ref.n_reads and got.n_windows == ref.n_windows
+        assert got.groups == ref.groups and got.contig_len == ref.contig_len and dict(got.errors) == dict(ref.errors)
+        assert np.array_equal(got.rows, ref.rows) and np.array_equal(got.pos, ref.pos) and np.array_equal(got.flags, ref.flags)
+    assert os.listdir(shm) == []
+
+
+def _bed(mo, backend, run):
+    eng = stream.StreamEngine(mo, backend)
+    run(eng)
+    beds = eng.finalize(None, None, write=False)
+    return {k: bytes(v) for k, v in beds.items()}, dict(eng.stats)
+
+
+def test_engine_fed_by_processes_equals_engine_fed_by_threads(tmp_path):
+    files = _files(tmp_path)
+    w = synth.synthetic_weights(26, 4.0)
+    mo = {'Base': 'C', 'outFolder': str(tmp_path / 'out'), 'fnum': 7, 'hidden': 100, 'windowsize': 21, 'feeder_slots': False}
+    os.makedirs(mo['outFolder'])
+    items = [files[i:i + 2] for i in range(0, len(files), 2)]
+    ref, st_ref = _bed(mo, OracleBackend(w), lambda eng: eng.run(iter(items), feeders=2))
+
+    ctx = multiprocessing.get_context('spawn')
+    with ctx.Manager() as mgr:
+        work = mgr.Queue()
+        for i, it in enumerate(items):
+            work.put((it, 0, i))
+        got, st = _bed(mo, OracleBackend(w), lambda eng: eng.run_processes(work, 2, 0, ctx))
+    assert got == ref and len(ref) > 0
+    assert st['reads'] == st_ref['reads'] and st['windows'] == st_ref['windows']
+    assert not os.path.exists(stream.shm_dir_for(mo))
+
+
+def test_slot_ring_hand_over(tmp_path):
+    files = _files(tmp_path)
+    w = synth.synthetic_weights(26, 4.0)
+    mo = {'Base': 'C', 'outFolder': str(tmp_path / 'out'), 'fnum': 7, 'hidden': 100, 'windowsize': 21, 'feeder_slot_mb': 1}
+    os.makedirs(mo['outFolder'])
+    items = [files[i:i + 1] for i in range(len(files))] * 3          # more batches than slots: slots are recycled
+    ref, st_ref = _bed(mo, OracleBackend(w), lambda eng: eng.run(iter(items), feeders=2))
+    ctx = multiprocessing.get_context('spawn')
+    backend = OracleBackend(w)
+    with ctx.Manager() as mgr:
+        work = mgr.Queue()
+        for i, it in enumerate(items):
+            work.put((it, 0, i))
+        got, st = _bed(mo, backend, lambda eng: eng.run_processes(work, 2, 0, ctx))
+    assert got == ref and st['reads'] == st_ref['reads']
+    assert st['slot_batches'] == len(items)                       # every batch went through a (recycled) slot
+    assert not os.path.exists(stream.shm_dir_for(mo))

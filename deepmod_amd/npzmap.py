@@ -1,0 +1,66 @@
+"""Zero-copy reader for the uncompressed `.npz` containers this package writes (feature / packed / raw containers).
+
+`numpy.load` on an `.npz` walks the zip directory per member, copies every member out of the archive and checks its CRC-32
+(~0.4 GB/s on the event tables of a raw container: 39 % of a feeder process' time).  The members of an archive written by
+`numpy.savez` are STORED, so each array is a contiguous `.npy` image inside the file: map the file once and hand out
+`numpy.frombuffer` views.  Compressed or object members fall back to `numpy.load`.  The arrays are read-only.
+"""
+from __future__ import annotations
+
+import mmap
+import struct
+import zipfile
+from typing import Dict
+
+import numpy as np
+from numpy.lib import format as npformat
+
+
+class _Cursor:
+    """Minimal file-like view of a mapped range for numpy's .npy header parser."""
+
+    def __init__(self, mm, pos):
+        self.mm, self.pos = mm, pos
+
+    def read(self, n):
+        out = self.mm[self.pos:self.pos + n]
+        self.pos += len(out)
+        return out
+
+
+def load(path: str) -> Dict[str, np.ndarray]:
+    """name -> array for every member of an .npz file; views into one read-only mapping where the member is stored."""
+    out: Dict[str, np.ndarray] = {}
+    fallback = []
+    with open(path, 'rb') as fh:
+        mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        with zipfile.ZipFile(fh) as zf:
+            infos = zf.infolist()
+    for info in infos:
+        name = info.filename[:-4] if info.filename.endswith('.npy') else info.filename
+        if info.compress_type != zipfile.ZIP_STORED:
+            fallback.append(name)
+            continue
+        ho = info.header_offset
+        if mm[ho:ho + 4] != b'PK\x03\x04':
+            fallback.append(name)
+            continue
+        n_name, n_extra = struct.unpack('<HH', mm[ho + 26:ho + 30])
+        cur = _Cursor(mm, ho + 30 + n_name + n_extra)
+        try:
+            version = npformat.read_magic(cur)
+            shape, fortran, dtype = (npformat.read_array_header_1_0(cur) if version == (1, 0) else npformat.read_array_header_2_0(cur))
+        except Exception:
+            fallback.append(name)
+            continue
+        if dtype.hasobject:
+            fallback.append(name)
+            continue
+        count = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
+        arr = np.frombuffer(mm, dtype, count, cur.pos)
+        out[name] = arr.reshape(shape, order='F' if fortran else 'C')
+    if fallback:
+        z = np.load(path, allow_pickle=False)
+        for name in fallback:
+            out[name] = z[name]
+    return out

@@ -120,9 +120,11 @@ def save_packed_container(path: str, reads: List[Dict], contig_len: Dict[str, in
 
 def load_packed(path: str) -> Dict:
     """-> {'tx', 'refbase', 'readbase', 'refbasei', 'evbase', 'row_off', 'bmi_off', 'ev_off', 'reads' (meta dicts),
-    'contig_len'} for either container format (format-1 files are converted on the fly)."""
-    z = np.load(path, allow_pickle=False)
-    if 'format' in z.files and int(z['format']) == 2:
+    'contig_len'} for either container format (format-1 files are converted on the fly).  The arrays of a format-2
+    container are read-only views into a mapping of the file (deepmod_amd/npzmap.py)."""
+    from . import npzmap
+    z = npzmap.load(path)
+    if 'format' in z and int(z['format']) == 2:
         meta = json.loads(str(z['meta']))
         out = {k: z[k] for k in ('tx', 'refbase', 'readbase', 'refbasei', 'evbase', 'row_off', 'bmi_off', 'ev_off')}
         out['reads'] = meta['reads']

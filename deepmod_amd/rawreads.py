@@ -28,33 +28,60 @@ EVENTS_DATA_DTYPE = [('mean', '<f8'), ('stdv', '<f8'), ('start', np.uint64), ('l
                      ('model_state', 'U5'), ('move', np.int64)]
 
 
+_EV_FIELDS = ('mean', 'stdv', 'start', 'length', 'model_state', 'move')
+
+
+class EventColumns:
+    """The basecaller's event table of one read as columns (views into the container's arrays): `ec['move']`, `len(ec)` -
+    what getEvent needs of the reference's structured `events_data` array, without building one per read."""
+    __slots__ = ('cols', 'n')
+
+    def __init__(self, cols: Dict[str, np.ndarray]):
+        self.cols = cols
+        self.n = len(cols['start'])
+
+    def __getitem__(self, name: str) -> np.ndarray:
+        return self.cols[name]
+
+    def __len__(self) -> int:
+        return self.n
+
+
 def save_raw_container(path: str, reads: List[Dict]) -> None:
-    """reads: dicts with read_id, raw (int16), events_data (EVENTS_DATA_DTYPE)."""
+    """reads: dicts with read_id, raw (int16), events_data (EVENTS_DATA_DTYPE or EventColumns).
+    Layout (format 2): the samples / event columns of all reads concatenated + offsets - nine arrays per container instead of
+    seven per read (the zip directory walk and per-member headers were 39 % of a feeder's time), uncompressed (inflating the
+    samples was 40 % before that)."""
     if not path.endswith(RAW_SUFFIX):
         raise ValueError('raw containers must end with ' + RAW_SUFFIX)
-    arrays = {}
-    metas = []
-    for i, rd in enumerate(reads):
-        ed = rd['events_data']
-        arrays['r%d_raw' % i] = np.asarray(rd['raw'], dtype=np.int16)
-        for f in ('mean', 'stdv', 'start', 'length', 'model_state', 'move'):
-            arrays['r%d_ev_%s' % (i, f)] = np.asarray(ed[f])
-        metas.append({'read_id': rd['read_id']})
-    arrays['meta'] = np.array(json.dumps(metas))
-    with open(path, 'wb') as fh:      # uncompressed: inflating the samples was 40 % of a streaming worker's host time
+    off = lambda parts: np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    raws = [np.asarray(rd['raw'], dtype=np.int16) for rd in reads]
+    arrays = {'format': np.array(2), 'raw': np.concatenate(raws) if raws else np.zeros(0, np.int16), 'raw_off': off(raws),
+              'ev_off': off([rd['events_data']['start'] for rd in reads]),
+              'meta': np.array(json.dumps([{'read_id': rd['read_id']} for rd in reads]))}
+    dtypes = dict(EVENTS_DATA_DTYPE)
+    for f in _EV_FIELDS:
+        cols = [np.asarray(rd['events_data'][f], dtype=dtypes[f]) for rd in reads]
+        arrays['ev_' + f] = np.concatenate(cols) if cols else np.zeros(0, dtypes[f])
+    with open(path, 'wb') as fh:
         np.savez(fh, **arrays)
 
 
 def load_raw_container(path: str) -> List[Dict]:
-    z = np.load(path, allow_pickle=False)
-    reads = []
-    for i, m in enumerate(json.loads(str(z['meta']))):
-        n = len(z['r%d_ev_start' % i])
-        ed = np.zeros(n, dtype=EVENTS_DATA_DTYPE)
-        for f in ('mean', 'stdv', 'start', 'length', 'model_state', 'move'):
-            ed[f] = z['r%d_ev_%s' % (i, f)]
-        reads.append({'read_id': m['read_id'], 'raw': z['r%d_raw' % i], 'events_data': ed})
-    return reads
+    """-> read dicts; the arrays are read-only views into a mapping of the file (deepmod_amd/npzmap.py)."""
+    from . import npzmap
+    z = npzmap.load(path)
+    metas = json.loads(str(z['meta']))
+    if 'format' not in z:                       # format 1: seven arrays per read
+        reads = []
+        for i, m in enumerate(metas):
+            reads.append({'read_id': m['read_id'], 'raw': z['r%d_raw' % i],
+                          'events_data': EventColumns({f: z['r%d_ev_%s' % (i, f)] for f in _EV_FIELDS})})
+        return reads
+    raw, ro, eo = z['raw'], z['raw_off'], z['ev_off']
+    cols = {f: z['ev_' + f] for f in _EV_FIELDS}
+    return [{'read_id': m['read_id'], 'raw': raw[ro[i]:ro[i + 1]],
+             'events_data': EventColumns({f: c[eo[i]:eo[i + 1]] for f, c in cols.items()})} for i, m in enumerate(metas)]
 
 
 def event_bases(model_state) -> np.ndarray:

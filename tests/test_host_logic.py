@@ -191,3 +191,22 @@ def test_c_bed_writer_equals_line_by_line_restatement(hip_lib):
                     counts[1][pos] += 1
                     counts[2][pos] += int(mp == 1)
     assert summary.bed_lines(case["chr"], case["strand"], case["Base"], *counts) == case["bed"].encode("ascii")
+
+
+def test_npzmap_views_equal_numpy_load(tmp_path):
+    """deepmod_amd/npzmap.py: zero-copy views of stored .npz members == numpy.load, compressed members fall back."""
+    from deepmod_amd import npzmap
+    rng = np.random.default_rng(3)
+    arrays = {'f32': rng.normal(size=(1000, 7)).astype(np.float32), 'i64': rng.integers(0, 1 << 40, 333), 'empty': np.zeros(0, np.int16),
+              'u5': np.array(['ACGTA', 'TTTTT', 'GGCAA']), 's1': np.frombuffer(b'ACGT-', 'S1'), 'scalar': np.array(2),
+              'meta': np.array('{"reads": [1, 2]}'), 'fortran': np.asfortranarray(rng.normal(size=(5, 4)))}
+    for name, saver in (('stored.npz', np.savez), ('deflated.npz', np.savez_compressed)):
+        path = str(tmp_path / name)
+        saver(path, **arrays)
+        got = npzmap.load(path)
+        assert sorted(got) == sorted(arrays)
+        for k, v in arrays.items():
+            assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), (name, k)
+        assert str(got['meta']) == str(arrays['meta']) and int(got['scalar']) == 2
+    stored = npzmap.load(str(tmp_path / 'stored.npz'))
+    assert not stored['f32'].flags.writeable                 # views into a read-only mapping

@@ -1,0 +1,61 @@
+"""GPU (-m gpu): the staging entry points of the streaming worker (include/deepmod_hip.h: dm_host_alloc / dm_host_free,
+dm_model_h2d_async, dm_model_mark / dm_model_wait_mark): a pipelined sequence of batches through page-locked staging sets gives
+the classes of plain synchronous calls, markers order host and device, and a range violation surfaces at the marker."""
+import numpy as np
+import pytest
+
+from deepmod_amd import _lib, model, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pipelined_staging_sets_equal_synchronous_calls(gpu_device):
+    w = synth.synthetic_weights(26, 4.0)
+    m = model.BiLSTMModel(w, device=gpu_device)
+    rng = np.random.default_rng(5)
+    batches = [synth.synthetic_windows(n, seed=int(s))[:, 10, :].copy() for n, s in ((5000, 1), (777, 2), (12001, 3), (64, 4), (3000, 5), (9000, 6))]
+    want = [m.predict_read(rows, 10, len(rows) - 20, want_prob=False)[1] for rows in batches]
+
+    m.set_option(_lib.DM_OPT_ASYNC, 1)
+    nset = 3
+    cap = max(len(b) for b in batches)
+    host = [model.PinnedArray(cap * 28, gpu_device) for _ in range(nset)]
+    dev = [model.DeviceArray((cap * 28,), np.uint8, gpu_device) for _ in range(nset)]
+    cls = [model.DeviceArray((cap,), np.uint8, gpu_device) for _ in range(len(batches))]
+    lib = _lib.load()
+    for k, rows in enumerate(batches):
+        i = k % nset
+        m.wait_mark(i)                                   # never recorded for the first nset batches: returns at once
+        host[i].view(np.float32, rows.size)[:] = rows.ravel()
+        _lib.check(lib.dm_model_h2d_async(m._h, dev[i].ptr, host[i].ptr, rows.nbytes))
+        m.predict_rows_device(dev[i].ptr, len(rows), 10, len(rows) - 20, cls[k].ptr + 10)
+        m.mark(i)
+    for i in range(nset):
+        m.wait_mark(i)
+    for k, rows in enumerate(batches):
+        got = cls[k].to_host()[10:len(rows) - 10]
+        assert np.array_equal(got, want[k]), k
+    with pytest.raises(_lib.DeepModHipError):
+        m.mark(8)
+    with pytest.raises(_lib.DeepModHipError):
+        m.wait_mark(-1)
+    for blk in host + dev + cls:
+        blk.free()
+    m.close()
+
+
+def test_range_violation_surfaces_at_the_marker(gpu_device):
+    w = synth.synthetic_weights(22, 4.0)
+    m = model.BiLSTMModel(w, device=gpu_device, precision="f16x3")
+    m.set_option(_lib.DM_OPT_ASYNC, 1)
+    rows = synth.synthetic_windows(400, seed=2)[:, 10, :].copy()
+    rows[200, 0] = 1.0e6
+    d = model.DeviceArray.from_host(rows, gpu_device)
+    c = model.DeviceArray((len(rows),), np.uint8, gpu_device)
+    m.predict_rows_device(d.ptr, len(rows), 10, len(rows) - 20, c.ptr + 10)
+    m.mark(0)
+    with pytest.raises(_lib.DeepModRangeError):
+        m.wait_mark(0)
+    m.wait_mark(0)                                       # reported once
+    m.sync()
+    m.close()

@@ -531,11 +531,11 @@ def _run_streaming_detect(moptions, ctx, pmanager, items, ngpu):
     # the host side of a batch is prepared by feeder PROCESSES of each rank (threads serialise on the interpreter lock): as
     # many as --threads asks for, within the CPUs this job may use (one is left to each rank's device queue)
     feeder_procs = max(1, min(feeders, (stream.usable_cpus() - world) // world)) if moptions.get('feeder_procs', 1) else 0
-    # raw containers: every feeder process normalises signals on the GPU (its own HIP context and queues).  Beyond ~8 such
-    # processes per GPU the hardware queues are oversubscribed and the classifier's queue gets time-sliced (measured: 8
-    # feeders 9.1e6 base-positions/s, 11 feeders 6.3e6 with the device queue waiting 2.9 of 4.3 s) - profiles/r02/README.md
+    # raw containers: the signal stage of all feeders runs in the GPU process (stream.signal_server).  Without it every
+    # feeder owns a HIP context, and beyond ~8 such processes per GPU the hardware queues are oversubscribed (8 feeders
+    # 9.1e6 base-positions/s, 11 feeders 6.3e6 with the device queue waiting 2.9 of 4.3 s - profiles/r02/README.md)
     from . import rawreads
-    if any(f.endswith(rawreads.RAW_SUFFIX) for it in items for f in it[0]):
+    if not run_opts.get('signal_server', True) and any(f.endswith(rawreads.RAW_SUFFIX) for it in items for f in it[0]):
         feeder_procs = min(feeder_procs, int(moptions.get('feeder_procs_raw', 8)))
     _run_processes(ctx, stream.stream_rank_main,
                    [(run_opts, r, world, r, work_q, result_q, feeders, feeder_procs) for r in range(world)], 'streaming detect')
@@ -568,7 +568,8 @@ def _print_stream_stats(stats, wall):
           + '; detect wall %.1f s, waiting for feeders %.1f s, merge + BED %.1f s per rank'
           % (tot['detect_wall'] / len(stats), tot['wait_feed'] / len(stats), tot['merge+bed'] / len(stats))
           + '; device queue: waiting for the device %.1f s, staging copy %.1f s, launches %.1f s'
-          % (tot['submit_wait_device'] / len(stats), tot['submit_stage'] / len(stats), tot['submit_launch'] / len(stats)))
+          % (tot['submit_wait_device'] / len(stats), tot['submit_stage'] / len(stats), tot['submit_launch'] / len(stats))
+          + ('; signal server %.1f s for %d requests' % (tot['signal_server'] / len(stats), tot['signal_requests']) if tot['signal_requests'] else ''))
 
 
 def _run_summary_jobs(moptions, ctx, pmanager, ngpu):

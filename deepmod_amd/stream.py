@@ -274,7 +274,149 @@ def shm_dir_for(moptions) -> str:
     return os.path.join(root, 'deepmod_amd_%d' % os.getpid())
 
 
-def feeder_process_main(moptions, work, ready, device: int, shm_dir: str, wid: int, free_slots=None, slot_bytes: int = 0):
+# ---------------------------------------------------------------------------------------------
+# signal server: feeder processes do not own a HIP context.  The signal statistics of a raw-container batch
+# (dm_signal_event_stats_batch) are computed by a thread of the GPU process: the feeder writes the samples and event tables
+# of its batch into a shared-memory request file and waits for the answer.  (Every feeder with its own context capped a
+# GPU at ~8 feeders: beyond that the hardware queues are oversubscribed and the classifier's queue is time-sliced.)
+# ---------------------------------------------------------------------------------------------
+def _sig_layout(n: int, n_raw: int, n_ev: int):
+    """byte offsets of [raw i16 | raw_off i64 | ev_off i64 | ev_start u64 | ev_length u64 || mean f32 | stdv f32 | norm6 f64 | first_empty i64]"""
+    up = lambda v: -(-v // 64) * 64
+    o = {}
+    pos = 0
+    for name, nbytes in (('raw', 2 * n_raw), ('raw_off', 8 * (n + 1)), ('ev_off', 8 * (n + 1)), ('ev_start', 8 * n_ev), ('ev_length', 8 * n_ev)):
+        o[name] = pos
+        pos = up(pos + nbytes)
+    o['in_end'] = pos
+    for name, nbytes in (('mean', 4 * n_ev), ('stdv', 4 * n_ev), ('norm6', 48 * n), ('first_empty', 8 * n)):
+        o[name] = pos
+        pos = up(pos + nbytes)
+    o['end'] = pos
+    return o
+
+
+class RemoteSignalNormalizer:
+    """Feeder-process side of the signal server: the interface of signal.SignalNormalizer that the raw path uses."""
+
+    def __init__(self, wid: int, shm_dir: str, requests, answers):
+        self.wid, self.requests, self.answers = wid, requests, answers
+        self.path = os.path.join(shm_dir, 'sig_%d' % wid)
+        self.mm = None
+        self.size = 0
+
+    def _ensure(self, nbytes: int):
+        import mmap
+        if nbytes > self.size:
+            if self.mm is not None:
+                self.mm.close()
+            size = max(1 << 22, int(nbytes * 1.5))
+            fd = os.open(self.path, os.O_CREAT | os.O_RDWR, 0o600)
+            try:
+                os.ftruncate(fd, size)
+                self.mm = mmap.mmap(fd, size)
+            finally:
+                os.close(fd)
+            self.size = size
+
+    def event_stats_batch(self, reads):
+        from . import _lib
+        if not reads:
+            return []
+        n = len(reads)
+        raw_off = np.concatenate([[0], np.cumsum([len(r[0]) for r in reads])]).astype(np.int64)
+        ev_off = np.concatenate([[0], np.cumsum([len(r[1]) for r in reads])]).astype(np.int64)
+        n_raw, n_ev = int(raw_off[-1]), int(ev_off[-1])
+        o = _sig_layout(n, n_raw, n_ev)
+        self._ensure(o['end'])
+        mm = self.mm
+        np.concatenate([np.asarray(r[0]) for r in reads], out=np.frombuffer(mm, np.int16, n_raw, o['raw']), casting='same_kind')
+        np.frombuffer(mm, np.int64, n + 1, o['raw_off'])[:] = raw_off
+        np.frombuffer(mm, np.int64, n + 1, o['ev_off'])[:] = ev_off
+        np.concatenate([np.asarray(r[1]) for r in reads], out=np.frombuffer(mm, np.uint64, n_ev, o['ev_start']), casting='same_kind')
+        np.concatenate([np.asarray(r[2]) for r in reads], out=np.frombuffer(mm, np.uint64, n_ev, o['ev_length']), casting='same_kind')
+        self.requests.put((self.wid, self.path, self.size, n, n_raw, n_ev))
+        err = self.answers.get()
+        if err is not None:
+            raise _lib.DeepModHipError(err)
+        mean = np.frombuffer(mm, np.float32, n_ev, o['mean']).copy()
+        stdv = np.frombuffer(mm, np.float32, n_ev, o['stdv']).copy()
+        norm6 = np.frombuffer(mm, np.float64, 6 * n, o['norm6']).reshape(n, 6)
+        first_empty = np.frombuffer(mm, np.int64, n, o['first_empty'])
+        keys = ("mshift", "mscale", "read_med", "read_mad", "lower_lim", "upper_lim")
+        return [(mean[ev_off[i]:ev_off[i + 1]], stdv[ev_off[i]:ev_off[i + 1]], dict(zip(keys, norm6[i].tolist())), int(first_empty[i]))
+                for i in range(n)]
+
+    def event_stats(self, raw, ev_start, ev_length, want_signal: bool = False):
+        if want_signal:
+            raise ValueError('the signal server returns event statistics only')
+        mean, stdv, norm, first_empty = self.event_stats_batch([(raw, ev_start, ev_length)])[0]
+        return mean, stdv, norm, first_empty, None
+
+    def close(self):
+        if self.mm is not None:
+            self.mm.close()
+            self.mm = None
+
+
+def signal_server(requests, answers, device: int, stats=None):
+    """Thread body in the GPU process: requests (wid, path, file size, n, n_raw, n_ev) until None; answers[wid] gets None or an
+    error text.  Inputs are copied to page-locked memory (uploads from the shared-memory mapping itself are slow), the C ABI
+    writes its results there, and they go back into the request file."""
+    import mmap
+    from . import _lib, model as dm, signal as dmsignal
+    norm = dmsignal.SignalNormalizer(device)
+    lib = norm._lib
+    maps = {}
+    pinned = None
+    try:
+        while True:
+            req = requests.get()
+            if req is None:
+                return
+            wid, path, size, n, n_raw, n_ev = req
+            t0 = time.perf_counter()
+            try:
+                if maps.get(wid, (None, 0))[1] != size:
+                    if wid in maps:
+                        maps[wid][0].close()
+                    fd = os.open(path, os.O_RDWR)
+                    try:
+                        maps[wid] = (mmap.mmap(fd, size), size)
+                    finally:
+                        os.close(fd)
+                mm = maps[wid][0]
+                o = _sig_layout(n, n_raw, n_ev)
+                if pinned is None or pinned.nbytes < o['end']:
+                    if pinned is not None:
+                        pinned.free()
+                    pinned = dm.PinnedArray(int(o['end'] * 1.5) + 4096, device)
+                pv = pinned.view(np.uint8, o['end'])
+                pv[:o['in_end']] = np.frombuffer(mm, np.uint8, o['in_end'])
+                base = pinned.ptr
+                rc = lib.dm_signal_event_stats_batch(norm._h, n, base + o['raw'], base + o['raw_off'], base + o['ev_start'], base + o['ev_length'],
+                                                     base + o['ev_off'], base + o['mean'], base + o['stdv'], base + o['norm6'], base + o['first_empty'])
+                if rc != 0:
+                    answers[wid].put(_lib.last_error())
+                    continue
+                np.frombuffer(mm, np.uint8, o['end'] - o['in_end'], o['in_end'])[:] = pv[o['in_end']:]
+                answers[wid].put(None)
+            except Exception as exc:                        # the feeder turns it into a per-read failure
+                answers[wid].put('signal server: %r' % (exc,))
+            if stats is not None:
+                stats['signal_server'] += time.perf_counter() - t0
+                stats['signal_requests'] += 1
+    finally:
+        for mm, _ in maps.values():
+            mm.close()
+        if pinned is not None:
+            pinned.free()
+        norm.close()
+
+
+
+def feeder_process_main(moptions, work, ready, device: int, shm_dir: str, wid: int, free_slots=None, slot_bytes: int = 0,
+                        sig_requests=None, sig_answers=None):
     """Body of one feeder process: file lists from `work` (a multiprocessing queue of (files, ...) items, filled before the
     run starts; empty = done) -> prepare_batch -> arrays into shared memory -> a small description on `ready`.
     Shared memory = one of the GPU process' page-locked slot files (`free_slots`: queue of slot numbers; the batch must fit
@@ -283,10 +425,13 @@ def feeder_process_main(moptions, work, ready, device: int, shm_dir: str, wid: i
     import traceback
     norm = []
 
-    def normalizer():                      # created on first use: only batches with raw containers need the device
+    def normalizer():                      # created on first use: only batches with raw containers need the signal stage
         if not norm:
-            from . import signal as dmsignal
-            norm.append(dmsignal.SignalNormalizer(device))
+            if sig_requests is not None:   # the GPU process' signal server: this process owns no HIP context
+                norm.append(RemoteSignalNormalizer(wid, shm_dir, sig_requests, sig_answers))
+            else:
+                from . import signal as dmsignal
+                norm.append(dmsignal.SignalNormalizer(device))
         return norm[0]
 
     slot_maps = {}
@@ -592,8 +737,17 @@ class StreamEngine:
                     os.close(fd)
             return slots[i]
 
-        procs = [ctx.Process(target=feeder_process_main, args=(self.mo, work, ready, device, shm_dir, i, free_slots, slot_bytes), daemon=True)
-                 for i in range(n_procs)]
+        sig_requests = sig_answers = server = None
+        if self.mo.get('signal_server', True) and hasattr(self.backend, 'device'):
+            sig_requests = ctx.Queue()
+            sig_answers = [ctx.Queue() for _ in range(n_procs)]
+            server = [threading.Thread(target=signal_server, args=(sig_requests, sig_answers, device, self.stats), daemon=True)
+                      for _ in range(max(1, int(self.mo.get('signal_servers', 2))))]     # each with its own dm_signal handle / stream
+            for th in server:
+                th.start()
+        procs = [ctx.Process(target=feeder_process_main, daemon=True,
+                             args=(self.mo, work, ready, device, shm_dir, i, free_slots, slot_bytes, sig_requests,
+                                   sig_answers[i] if sig_answers else None)) for i in range(n_procs)]
         for pr in procs:
             pr.start()
         try:
@@ -627,6 +781,11 @@ class StreamEngine:
                 pr.join(timeout=10)
                 if pr.is_alive():
                     pr.terminate()
+            if server is not None:
+                for _ in server:
+                    sig_requests.put(None)
+                for th in server:
+                    th.join(timeout=10)
             shutil.rmtree(shm_dir, ignore_errors=True)
         self.stats['detect_wall'] += time.perf_counter() - t_start
         for k, v in getattr(self.backend, 'timing', {}).items():

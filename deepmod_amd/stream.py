@@ -750,6 +750,7 @@ class StreamEngine:
                                    sig_answers[i] if sig_answers else None)) for i in range(n_procs)]
         for pr in procs:
             pr.start()
+        clean = False
         try:
             done = 0
             while done < n_procs:
@@ -776,10 +777,12 @@ class StreamEngine:
             t0 = time.perf_counter()
             self.backend.sync()
             self.stats['drain'] += time.perf_counter() - t0
+            clean = True
         finally:
             for pr in procs:
-                pr.join(timeout=10)
-                if pr.is_alive():
+                if clean:                # every feeder has sent its end marker: it is on its way out
+                    pr.join(timeout=10)
+                if pr.is_alive():        # the run is failing (or a feeder hangs): feeders may be blocked on a queue for good
                     pr.terminate()
             if server is not None:
                 for _ in server:

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libdeepmod_hip.so")
 DM_OPT_PROFILE = 1
 DM_OPT_PRECISION = 2
 DM_OPT_ASYNC = 3
+DM_OPT_RESERVED_CUS = 4
 DM_PREC_F32 = 0
 DM_PREC_F16X3 = 1
 DM_PREC_F16X3_LM = 2   # layer-major split-f16 kernel of round 1 (same arithmetic; the default is measured against it)

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "../../include/deepmod_hip.h"
@@ -846,6 +847,10 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
             return DM_OK;
         case DM_OPT_ASYNC:
             m->async = value != 0;
+            return DM_OK;
+        case DM_OPT_RESERVED_CUS:
+            if (value < 0 || value > m->num_cu / 2) return fail(DM_EINVAL, "reserved CUs %lld outside [0, %d]", (long long)value, m->num_cu / 2);
+            m->grid_cap = m->num_cu - int(value);
             return DM_OK;
         case DM_OPT_PRECISION:
             if (value != DM_PREC_F32 && value != DM_PREC_F16X3 && value != DM_PREC_F16X3_LM) return fail(DM_EINVAL, "unknown precision %lld", (long long)value);

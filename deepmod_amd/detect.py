@@ -569,7 +569,8 @@ def _print_stream_stats(stats, wall):
           % (tot['detect_wall'] / len(stats), tot['wait_feed'] / len(stats), tot['merge+bed'] / len(stats))
           + '; device queue: waiting for the device %.1f s, staging copy %.1f s, launches %.1f s'
           % (tot['submit_wait_device'] / len(stats), tot['submit_stage'] / len(stats), tot['submit_launch'] / len(stats))
-          + ('; signal server %.1f s for %d requests' % (tot['signal_server'] / len(stats), tot['signal_requests']) if tot['signal_requests'] else ''))
+          + ('; signal server %.1f s (%.1f s inside dm_signal_event_stats_batch) for %d requests'
+             % (tot['signal_server'] / len(stats), tot['signal_server_call'] / len(stats), tot['signal_requests']) if tot['signal_requests'] else ''))
 
 
 def _run_summary_jobs(moptions, ctx, pmanager, ngpu):

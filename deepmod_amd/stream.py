@@ -394,8 +394,11 @@ def signal_server(requests, answers, device: int, stats=None):
                 pv = pinned.view(np.uint8, o['end'])
                 pv[:o['in_end']] = np.frombuffer(mm, np.uint8, o['in_end'])
                 base = pinned.ptr
+                t1 = time.perf_counter()
                 rc = lib.dm_signal_event_stats_batch(norm._h, n, base + o['raw'], base + o['raw_off'], base + o['ev_start'], base + o['ev_length'],
                                                      base + o['ev_off'], base + o['mean'], base + o['stdv'], base + o['norm6'], base + o['first_empty'])
+                if stats is not None:
+                    stats['signal_server_call'] += time.perf_counter() - t1
                 if rc != 0:
                     answers[wid].put(_lib.last_error())
                     continue
@@ -528,6 +531,10 @@ class HipBackend:
             self.sess, dm.latest_checkpoint(moptions['modfile'][1]) or moptions['modfile'][0])
         self.model = self.sess.model
         self.model.set_option(_lib.DM_OPT_ASYNC, 1)
+        # CUs left to the signal server's kernels (DM_OPT_RESERVED_CUS).  Measured: behind a classifier launch that holds every CU
+        # the histogram kernel of a 40-read request takes 1.9 ms instead of 0.15 ms, but with 32 CUs reserved the classifier is
+        # 4.5 % slower and the end-to-end rate no better (profiles/r02/README.md): default 0
+        self.model.set_option(_lib.DM_OPT_RESERVED_CUS, int(moptions.get('reserved_cus', os.environ.get('DEEPMOD_RESERVED_CUS', 0))))
         self._dm = dm
         self._sets = [{'host': None, 'dev': None} for _ in range(self.NSET)]
         self._k = 0
@@ -742,7 +749,7 @@ class StreamEngine:
             sig_requests = ctx.Queue()
             sig_answers = [ctx.Queue() for _ in range(n_procs)]
             server = [threading.Thread(target=signal_server, args=(sig_requests, sig_answers, device, self.stats), daemon=True)
-                      for _ in range(max(1, int(self.mo.get('signal_servers', 2))))]     # each with its own dm_signal handle / stream
+                      for _ in range(max(1, int(self.mo.get('signal_servers', os.environ.get('DEEPMOD_SIGNAL_SERVERS', 2)))))]     # each with its own dm_signal handle / stream
             for th in server:
                 th.start()
         procs = [ctx.Process(target=feeder_process_main, daemon=True,

@@ -57,6 +57,9 @@ extern "C" {
 #define DM_OPT_PRECISION 2 /* DM_PREC_*; default DM_PREC_F16X3 */
 #define DM_OPT_ASYNC 3     /* 1: dm_predict_* with device-resident buffers return after enqueue on the model's stream;
                               wait with dm_model_sync.  Default 0: every call is synchronous on return. */
+#define DM_OPT_RESERVED_CUS 4 /* n in [0, CUs / 2]: the classifier's persistent grid uses CUs - n workgroups (one per CU), so that
+                              small kernels of OTHER streams (the signal stage of the streaming worker) run beside a classifier
+                              launch instead of waiting for it to drain.  Default 0. */
 #define DM_PREC_F32 0      /* fp32 MFMA (v_mfma_f32_16x16x4_f32): fp32 products, the TF graph's own arithmetic */
 #define DM_PREC_F16X3 1    /* split-f16 MFMA: every fp32 operand = hi + lo f16, 3 products per fp32 product, fp32
                               accumulation; max |dp| vs the oracle 1e-6 .. 2e-6 (tolerance of the path: 1e-4), ~3x faster.

@@ -49,7 +49,7 @@ def build(names):
     src = os.path.join(ROOT, "deepmod_amd", "csrc", "deepmod_hip.hip")
     for name in names:
         out = os.path.join(ABL, "lib_%s.so" % name)
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form", "-o", out, src,
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-mllvm", "-amdgpu-mfma-vgpr-form", "-o", out, src,
                "-ldl"] + VARIANTS[name]
         subprocess.check_call(cmd, cwd=os.path.dirname(src))
         print("built", out)

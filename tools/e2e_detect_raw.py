@@ -31,7 +31,7 @@ if __name__ == "__main__":
     os.makedirs(tmp + "/model")
     synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)
     cmd = [sys.executable, os.path.join(ROOT, "bin", "DeepMod.py"), "detect", "--wrkBase", wrk, "--Ref", wrk + "/genome.fa", "--modfile", prefix,
-           "--outFolder", tmp + "/out", "--Base", "C", "--gpus", "1", "--threads", str(threads), "--files_per_thread", "4", "--FileID", "raw", "--alignStr", "minimap2"]
+           "--outFolder", tmp + "/out", "--Base", "C", "--gpus", "1", "--threads", str(threads), "--files_per_thread", "4", "--FileID", "raw", "--alignStr", "minimap2"] + sys.argv[3:]
     t0 = time.time()
     res = subprocess.run(cmd, capture_output=True, text=True)
     wall = time.time() - t0

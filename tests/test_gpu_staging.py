@@ -59,3 +59,19 @@ def test_range_violation_surfaces_at_the_marker(gpu_device):
     m.wait_mark(0)                                       # reported once
     m.sync()
     m.close()
+
+
+def test_reserved_cus_do_not_change_results(gpu_device):
+    """DM_OPT_RESERVED_CUS shrinks the persistent grid of every classifier kernel; results are those of the full grid."""
+    w = synth.synthetic_weights(26, 4.0)
+    x = synth.synthetic_windows(70000, seed=9)             # more work items than workgroups for every kernel
+    for prec in ("f16x3", "f16x3lm", "f32"):
+        m = model.BiLSTMModel(w, device=gpu_device, precision=prec)
+        p0, c0 = m.predict_windows(x)
+        m.set_option(_lib.DM_OPT_RESERVED_CUS, 32)
+        p1, c1 = m.predict_windows(x)
+        assert np.array_equal(c0, c1) and np.array_equal(p0, p1), prec
+        for bad in (-1, 100000):
+            with pytest.raises(_lib.DeepModHipError):
+                m.set_option(_lib.DM_OPT_RESERVED_CUS, bad)
+        m.close()

@@ -21,6 +21,22 @@ EVENT_DTYPE = [('mean', '<f4'), ('stdv', '<f4'), ('start', np.uint64), ('length'
 BMI_DTYPE = [('refbase', 'U1'), ('readbase', 'U1'), ('refbasei', np.uint64), ('readbasei', np.uint64), ('mod_pred', int)]
 
 
+def s1_to_u1(a) -> np.ndarray:
+    """'S1' -> 'U1' through the code points (numpy's own string cast converts element by element: 20x slower)."""
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.dtype('U1'):
+        return a
+    return a.view(np.uint8).astype(np.uint32).view('U1')
+
+
+def u1_to_s1(a) -> np.ndarray:
+    """'U1' (ASCII) -> 'S1' through the code points."""
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.dtype('S1'):
+        return a
+    return a.view(np.uint32).astype(np.uint8).view('S1')
+
+
 def make_base_map_info(refbase, readbase, refbasei, readbasei=None, mod_pred=None) -> np.ndarray:
     n = len(refbase)
     bmi = np.zeros(n, dtype=BMI_DTYPE)
@@ -50,8 +66,8 @@ def save_feature_container(path: str, reads: List[Dict]) -> None:
     for i, rd in enumerate(reads):
         bmi = rd['base_map_info']
         arrays['r%d_mfeatures' % i] = np.asarray(rd['mfeatures'], dtype=np.float64)
-        arrays['r%d_refbase' % i] = bmi['refbase'].astype('U1')
-        arrays['r%d_readbase' % i] = bmi['readbase'].astype('U1')
+        arrays['r%d_refbase' % i] = s1_to_u1(bmi['refbase'])
+        arrays['r%d_readbase' % i] = s1_to_u1(bmi['readbase'])
         arrays['r%d_refbasei' % i] = bmi['refbasei'].astype(np.uint64)
         arrays['r%d_readbasei' % i] = bmi['readbasei'].astype(np.uint64)
         arrays['r%d_evbase' % i] = np.array([s[2] for s in rd['events']['model_state']], dtype='U1')
@@ -104,8 +120,8 @@ def save_packed_container(path: str, reads: List[Dict], contig_len: Dict[str, in
         else:
             bmi = rd['base_map_info']
             tx.append(np.asarray(rd['mfeatures'][:, 3:], np.float32))
-            refb.append(bmi['refbase'].astype('S1'))
-            readb.append(bmi['readbase'].astype('S1'))
+            refb.append(u1_to_s1(bmi['refbase']))
+            readb.append(u1_to_s1(bmi['readbase']))
             refi.append(bmi['refbasei'].astype(np.int64))
             evb.append(np.array([s[2] for s in rd['events']['model_state']], dtype='S1'))
         metas.append({k: rd[k] for k in ('readk', 'chr', 'strand', 'mapped_start', 'start_clip', 'end_clip')})
@@ -132,10 +148,10 @@ def load_packed(path: str) -> Dict:
         return out
     metas = json.loads(str(z['meta']))
     tx = [z['r%d_mfeatures' % i][:, 3:].astype(np.float32) for i in range(len(metas))]
-    refb = [z['r%d_refbase' % i].astype('S1') for i in range(len(metas))]
-    readb = [z['r%d_readbase' % i].astype('S1') for i in range(len(metas))]
+    refb = [u1_to_s1(z['r%d_refbase' % i]) for i in range(len(metas))]
+    readb = [u1_to_s1(z['r%d_readbase' % i]) for i in range(len(metas))]
     refi = [z['r%d_refbasei' % i].astype(np.int64) for i in range(len(metas))]
-    evb = [z['r%d_evbase' % i].astype('S1') for i in range(len(metas))]
+    evb = [u1_to_s1(z['r%d_evbase' % i]) for i in range(len(metas))]
     off = lambda parts: np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
     cat = lambda parts, dt, shape: np.concatenate(parts) if parts else np.zeros(shape, dt)
     return {'tx': cat(tx, np.float32, (0, 7)), 'refbase': cat(refb, 'S1', 0), 'readbase': cat(readb, 'S1', 0),
@@ -156,11 +172,11 @@ def _classic_reads(pk: Dict) -> List[Dict]:
         rd['mfeatures'] = mf
         sl = slice(bo[i], bo[i + 1])
         refi = pk['refbasei'][sl].astype(np.uint64)
-        readb = pk['readbase'][sl].astype('U1')
+        readb = s1_to_u1(pk['readbase'][sl])
         ng = readb != '-'
-        rd['base_map_info'] = make_base_map_info(pk['refbase'][sl].astype('U1'), readb, refi,
+        rd['base_map_info'] = make_base_map_info(s1_to_u1(pk['refbase'][sl]), readb, refi,
                                                  (np.cumsum(ng) - ng).astype(np.uint64))
-        rd['events'] = events_from_bases(pk['evbase'][eo[i]:eo[i + 1]].astype('U1'))
+        rd['events'] = events_from_bases(s1_to_u1(pk['evbase'][eo[i]:eo[i + 1]]))
         reads.append(rd)
     return reads
 
@@ -193,7 +209,7 @@ class PredWriter:
         key = 'pred_' + str(self.n)
         self.n += 1
         for f in ('refbase', 'readbase'):
-            self.arrays[key + '/' + f] = bmi[f].astype('S1')
+            self.arrays[key + '/' + f] = u1_to_s1(bmi[f])
         self.arrays[key + '/refbasei'] = bmi['refbasei'].astype(np.uint64)
         self.arrays[key + '/readbasei'] = bmi['readbasei'].astype(np.uint64)
         self.arrays[key + '/mod_pred'] = bmi['mod_pred'].astype(np.int64)
@@ -233,6 +249,6 @@ def read_pred(path: str, key: str):
         z = np.load(path, allow_pickle=False)
         _cache.update(path=path, z=z, attrs=json.loads(str(z['attrs'])))
     z, attrs = _cache['z'], _cache['attrs']
-    m_pred = make_base_map_info(z[key + '/refbase'].astype('U1'), z[key + '/readbase'].astype('U1'),
+    m_pred = make_base_map_info(s1_to_u1(z[key + '/refbase']), s1_to_u1(z[key + '/readbase']),
                                 z[key + '/refbasei'], z[key + '/readbasei'], z[key + '/mod_pred'])
     return m_pred, attrs[key]['mapped_chr'], attrs[key]['mapped_strand']

@@ -96,7 +96,7 @@ def map_read(flag: int, pos1: int, cigar: str, readseq: str, refseq, n_events: i
            'num_mismatches': int(info[_lib.DM_MAP_NUM_MISMATCH])}
     if out['status'] == _lib.DM_MAP_OK:
         n = int(info[_lib.DM_MAP_N_ROWS])
-        out['base_map_info'] = predstore.make_base_map_info(refb[:n].astype('U1'), readb[:n].astype('U1'), refi[:n], readi[:n])
+        out['base_map_info'] = predstore.make_base_map_info(predstore.s1_to_u1(refb[:n]), predstore.s1_to_u1(readb[:n]), refi[:n], readi[:n])
         out['table_s1'] = (refb[:n], readb[:n], refi[:n].astype(np.int64))      # the same columns as the C walk wrote them (streaming path)
         out.update(leftclip=int(info[_lib.DM_MAP_LEFTCLIP]), rightclip=int(info[_lib.DM_MAP_RIGHTCLIP]),
                    ev_lo=int(info[_lib.DM_MAP_EV_LO]), ev_hi=int(info[_lib.DM_MAP_EV_HI]),

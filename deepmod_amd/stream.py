@@ -124,10 +124,10 @@ def rows_from_reads(reads: Iterable[Dict], base: str, src: str, out: Prepared) -
             rb, qb, ri = rd['table_s1']
             refb.append(rb); readb.append(qb); refi.append(ri)
         else:
-            refb.append(bmi['refbase'].astype('S1'))
-            readb.append(bmi['readbase'].astype('S1'))
+            refb.append(predstore.u1_to_s1(bmi['refbase']))
+            readb.append(predstore.u1_to_s1(bmi['readbase']))
             refi.append(bmi['refbasei'].astype(np.int64))
-        evb.append(rawreads.event_bases(rd['events']['model_state']).astype('S1'))
+        evb.append(predstore.u1_to_s1(rawreads.event_bases(rd['events']['model_state'])))
         metas.append(rd)
     off = lambda parts: np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
     pk = {'tx': np.concatenate(tx), 'refbase': np.concatenate(refb), 'readbase': np.concatenate(readb),

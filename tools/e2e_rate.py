@@ -49,3 +49,7 @@ print("%s containers: %d reads, %d rows (%d windows): prepare %.3f s = %.3g rows
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(26)
 print('\n'.join(s.getvalue().splitlines()[4:44]))
+if os.environ.get('DM_PROFILE_CALLERS'):
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats('tottime').print_callers(os.environ['DM_PROFILE_CALLERS'])
+    print(s.getvalue()[:3000])

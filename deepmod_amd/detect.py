@@ -28,7 +28,7 @@ from collections import defaultdict
 
 import numpy as np
 
-from . import predstore, rawreads, readmap
+from . import _lib, predstore, rawreads, readmap
 
 rnn_pred_batch_size = 512   # myDetect.py:30
 pre_base_str = 'rnn.pred.ind'  # myDetect.py:33-ish: index-file stem used by the manager and workers
@@ -96,6 +96,21 @@ def scatter_predictions(modevents, base_map_info, start_clip, n, mfpred_output):
     return int(len(hit))
 
 
+def predict_rows_any_range(model, rows, first, count):
+    """dm_predict_read -> classes.  The split-f16 kernel refuses inputs outside its range (DM_ERANGE: an event length beyond
+    65504 * 2^k samples, a feature beyond +-65504, NaN) instead of clamping them; the reference computes such a read in fp32
+    like any other, so the call is repeated with the fp32 kernel."""
+    try:
+        return model.predict_read(rows, first, count, want_prob=False)[1]
+    except _lib.DeepModRangeError:
+        keep = model.get_info(_lib.DM_INFO_PRECISION)
+        model.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F32)
+        try:
+            return model.predict_read(rows, first, count, want_prob=False)[1]
+        finally:
+            model.set_option(_lib.DM_OPT_PRECISION, keep)
+
+
 def mPredict_batch(moptions, sp_options, reads):
     """Classify several reads with ONE device call.  A read of n aligned bases is only n/128 tiles and
     every tile has a fixed latency, so per-read calls (the reference's granularity, mPredict1) leave most
@@ -115,7 +130,7 @@ def mPredict_batch(moptions, sp_options, reads):
         off += len(tx)
     rows = np.concatenate(mats)
     sess.run(init_l)
-    _, cls = sess.model.predict_read(rows, half, len(rows) - 2 * half, want_prob=False)
+    cls = predict_rows_any_range(sess.model, rows, half, len(rows) - 2 * half)
     out = []
     for rd, (first, n) in zip(reads, spans):
         if n <= 0:

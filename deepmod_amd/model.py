@@ -263,7 +263,16 @@ class Session:
         if feed_dict is None or self.graph.X not in feed_dict:
             raise ValueError("feed_dict must provide X")
         x = np.asarray(feed_dict[self.graph.X])
-        prob, cls = self.model.predict_windows(x, want_prob=any(f is self.graph.prediction for f in flist))
+        want_prob = any(f is self.graph.prediction for f in flist)
+        try:
+            prob, cls = self.model.predict_windows(x, want_prob=want_prob)
+        except _lib.DeepModRangeError:        # the split-f16 kernel refuses what it cannot represent; TensorFlow computes it in fp32
+            keep = self.model.get_info(_lib.DM_INFO_PRECISION)
+            self.model.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F32)
+            try:
+                prob, cls = self.model.predict_windows(x, want_prob=want_prob)
+            finally:
+                self.model.set_option(_lib.DM_OPT_PRECISION, keep)
         out = []
         for f in flist:
             if f is self.graph.mfpred:

@@ -38,7 +38,7 @@ HALF = 10          # windowsize // 2
 
 class Prepared:
     """One worker batch, ready for the device.  Rows of the reads are concatenated, reads grouped by (contig, strand)."""
-    __slots__ = ('rows', 'pos', 'flags', 'n_rows', 'groups', 'n_windows', 'n_reads', 'errors', 'contig_len', 'timing', 'files', 'on_done')
+    __slots__ = ('rows', 'pos', 'flags', 'n_rows', 'groups', 'n_windows', 'n_reads', 'errors', 'contig_len', 'timing', 'files', 'on_done', 'f32')
 
     def __init__(self):
         self.rows = np.zeros((0, 7), np.float32)
@@ -52,6 +52,7 @@ class Prepared:
         self.contig_len: Dict[str, int] = {}
         self.timing: Dict[str, float] = defaultdict(float)
         self.files: List[str] = []
+        self.f32 = False             # a feature outside the split-f16 kernel's range (or NaN): this batch runs the fp32 kernel
         self.on_done = None          # called once the device has consumed the host arrays (a feeder slot goes back to its queue)
 
 
@@ -173,7 +174,17 @@ def finish(out: Prepared, alloc=None) -> Prepared:
         out.flags = np.concatenate(flags + xflags)
     out.n_rows = r
     out._pieces = []
+    out.f32 = not in_f16_range(out.rows)
     return out
+
+
+def in_f16_range(rows: np.ndarray) -> bool:
+    """True if the split-f16 kernel takes these feature rows (include/deepmod_hip.h: |x| <= 65504; an event length may go up
+    to 65504 * 2^k, but a read with an event that long is rare enough to take the fp32 kernel with the rest of its batch).
+    NaN compares false: not in range."""
+    if rows.size == 0:
+        return True
+    return bool(rows.max() <= 65504.0) and bool(rows.min() >= -65504.0)
 
 
 class _PreparedBuilder(Prepared):
@@ -476,7 +487,7 @@ def feeder_process_main(moptions, work, ready, device: int, shm_dir: str, wid: i
             pb = prepare_batch(moptions, files, normalizer, alloc)
             meta = {'path': path if 'mm' in holder else None, 'slot': holder.get('slot'), 'n_rows': pb.n_rows, 'n_pos': len(pb.pos),
                     'groups': pb.groups, 'n_windows': pb.n_windows, 'n_reads': pb.n_reads, 'errors': {k: list(v) for k, v in pb.errors.items()},
-                    'contig_len': dict(pb.contig_len), 'timing': dict(pb.timing), 'files': list(pb.files)}
+                    'contig_len': dict(pb.contig_len), 'timing': dict(pb.timing), 'files': list(pb.files), 'f32': pb.f32}
             pb.rows = pb.pos = pb.flags = None          # drop the views before a mapping goes away
             if 'mm' in holder:
                 holder['mm'].close()
@@ -499,6 +510,7 @@ def prepared_from_shm(meta, slot_buffer=None) -> Prepared:
     for k, v in meta['timing'].items():
         pb.timing[k] += v
     pb.files = meta['files']
+    pb.f32 = bool(meta.get('f32', False))
     if meta.get('slot') is not None:
         pb.rows, pb.pos, pb.flags = _shm_views(slot_buffer(meta['slot']), meta['n_rows'], meta['n_pos'])
     elif meta['path'] is not None:
@@ -531,6 +543,8 @@ class HipBackend:
             self.sess, dm.latest_checkpoint(moptions['modfile'][1]) or moptions['modfile'][0])
         self.model = self.sess.model
         self.model.set_option(_lib.DM_OPT_ASYNC, 1)
+        self._lib_mod = _lib
+        self._precision = self.model.get_info(_lib.DM_INFO_PRECISION)
         # CUs left to the signal server's kernels (DM_OPT_RESERVED_CUS).  Measured: behind a classifier launch that holds every CU
         # the histogram kernel of a 40-read request takes 1.9 ms instead of 0.15 ms, but with 32 CUs reserved the classifier is
         # 4.5 % slower and the end-to-end rate no better (profiles/r02/README.md): default 0
@@ -584,7 +598,13 @@ class HipBackend:
         self._lib_check(self._lib.dm_model_h2d_async(self.model._h, dev.ptr, host.ptr, end))
         d_rows, d_pos, d_flags, d_cls = dev.ptr, dev.ptr + o_pos, dev.ptr + o_flags, dev.ptr + o_cls
         # window centred on row r -> cls[r]; rows 0..9 and R-10..R-1 are padding of the first / last read
-        self.model.predict_rows_device(d_rows, R, HALF, R - 2 * HALF, d_cls + HALF)
+        if pb.f32 and self._precision != self._lib_mod.DM_PREC_F32:      # launches are queued in order: the switch covers this batch only
+            self.model.set_option(self._lib_mod.DM_OPT_PRECISION, self._lib_mod.DM_PREC_F32)
+            self.model.predict_rows_device(d_rows, R, HALF, R - 2 * HALF, d_cls + HALF)
+            self.model.set_option(self._lib_mod.DM_OPT_PRECISION, self._precision)
+            self.timing['f32_batches'] += 1
+        else:
+            self.model.predict_rows_device(d_rows, R, HALF, R - 2 * HALF, d_cls + HALF)
         for (c, s, lo, hi, xlo, xhi) in pb.groups:
             summ = summaries(c, s, pb.contig_len.get(c, 0))
             summ.add_classified_device(d_pos + 8 * lo, d_flags + lo, d_cls + lo, hi - lo)

@@ -75,3 +75,57 @@ def test_reserved_cus_do_not_change_results(gpu_device):
             with pytest.raises(_lib.DeepModHipError):
                 m.set_option(_lib.DM_OPT_RESERVED_CUS, bad)
         m.close()
+
+
+def test_streaming_batches_outside_the_f16_range_take_the_fp32_kernel(tmp_path, gpu_device):
+    """A read with an event length no f16 scheme can carry (1e9 samples) and a NaN feature: the streaming engine runs the
+    batch that holds it with the fp32 kernel (host-side range check in the feeder) and its BED equals an all-fp32 run; the
+    reference-shaped session adapter and the stored path's batched call fall back per call."""
+    import os
+    from deepmod_amd import detect, predstore, stream, synth_reads
+    files = synth_reads.write_synthetic_run(str(tmp_path / 'in'), n_reads=8, reads_per_file=2, genome_len=6000, seed=3, chrom='chrA',
+                                            min_len=200, max_len=500)
+    pk = predstore.load_packed(files[1])
+    tx = np.array(pk['tx'])
+    tx[int(pk['row_off'][0]) + 150, 6] = 1.0e9
+    tx[int(pk['row_off'][1]) + 160, 4] = np.nan
+    reads = []
+    for i, meta in enumerate(pk['reads']):
+        ro, bo, eo = pk['row_off'], pk['bmi_off'], pk['ev_off']
+        reads.append(dict(meta, tx=tx[ro[i]:ro[i + 1]], refbase=pk['refbase'][bo[i]:bo[i + 1]], readbase=pk['readbase'][bo[i]:bo[i + 1]],
+                          refbasei=pk['refbasei'][bo[i]:bo[i + 1]], evbase=pk['evbase'][eo[i]:eo[i + 1]]))
+    predstore.save_packed_container(files[1], reads, pk['contig_len'])
+    prefix = str(tmp_path / 'model' / 'm')
+    os.makedirs(os.path.dirname(prefix))
+    synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)
+    mo = {'fnum': 7, 'hidden': 100, 'windowsize': 21, 'modfile': [prefix, os.path.dirname(prefix) + '/'], 'outFolder': str(tmp_path / 'out'),
+          'Base': 'C'}
+    os.makedirs(mo['outFolder'])
+    beds = {}
+    for name, env in (('default', None), ('f32', 'f32')):
+        if env:
+            os.environ['DEEPMOD_PRECISION'] = env
+        try:
+            backend = stream.HipBackend(mo, gpu_device)
+            eng = stream.StreamEngine(mo, backend)
+            eng.run(iter([files[:2], files[2:]]), feeders=1)
+            beds[name] = {k: bytes(v) for k, v in eng.finalize(None, None, write=False).items()}
+            n_f32 = eng.stats['submit_f32_batches']
+            backend.close()
+        finally:
+            os.environ.pop('DEEPMOD_PRECISION', None)
+        assert n_f32 == (1 if name == 'default' else 0)          # only the batch with the poisoned container switches kernels
+    assert beds['default'] == beds['f32'] and len(beds['f32']) > 0
+
+    # the per-call fallbacks: dm_predict_read on the poisoned rows, and the sess.run seam on materialised windows
+    from deepmod_amd import model as dm
+    w = synth.synthetic_weights(26, 4.0)
+    m = dm.BiLSTMModel(w, device=gpu_device)
+    rows = np.ascontiguousarray(tx[:600], np.float32)
+    with pytest.raises(_lib.DeepModRangeError):
+        m.predict_read(rows, 10, len(rows) - 20)
+    got = detect.predict_rows_any_range(m, rows, 10, len(rows) - 20)
+    assert m.get_info(_lib.DM_INFO_PRECISION) == _lib.DM_PREC_F16X3          # restored
+    m.set_precision('f32')
+    assert np.array_equal(got, m.predict_read(rows, 10, len(rows) - 20, want_prob=False)[1])
+    m.close()

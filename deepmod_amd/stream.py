@@ -281,7 +281,15 @@ def usable_cpus() -> int:
 
 
 def shm_dir_for(moptions) -> str:
-    root = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else moptions['outFolder']
+    """Directory of the hand-over files of this GPU process: /dev/shm when it has room (a container's default 64 MB tmpfs does
+    not hold one batch), else the output folder (the files then go through the page cache of that file system)."""
+    root = moptions['outFolder']
+    try:
+        st = os.statvfs('/dev/shm')
+        if os.access('/dev/shm', os.W_OK) and st.f_bavail * st.f_frsize >= (2 << 30):
+            root = '/dev/shm'
+    except OSError:
+        pass
     return os.path.join(root, 'deepmod_amd_%d' % os.getpid())
 
 

@@ -733,9 +733,10 @@ class StreamEngine:
         for k, v in getattr(self.backend, 'timing', {}).items():
             self.stats['submit_' + k] += v
 
-    def run_processes(self, work, n_procs: int, device: int, ctx=None):
+    def run_processes(self, work, n_procs: int, device: int, ctx=None, make_backend=None):
         """Same as run(), with the batches prepared by `n_procs` feeder processes that drain `work` (a multiprocessing queue
-        of (files, ...) items shared by all ranks and filled before the run starts)."""
+        of (files, ...) items shared by all ranks and filled before the run starts).  make_backend: create the device backend
+        only after the feeders have been started, so that they prepare the first batches while the model loads."""
         import multiprocessing
         import shutil
         t_start = time.perf_counter()
@@ -773,7 +774,7 @@ class StreamEngine:
             return slots[i]
 
         sig_requests = sig_answers = server = None
-        if self.mo.get('signal_server', True) and hasattr(self.backend, 'device'):
+        if self.mo.get('signal_server', True) and (make_backend is not None or hasattr(self.backend, 'device')):
             sig_requests = ctx.Queue()
             sig_answers = [ctx.Queue() for _ in range(n_procs)]
             server = [threading.Thread(target=signal_server, args=(sig_requests, sig_answers, device, self.stats), daemon=True)
@@ -787,6 +788,10 @@ class StreamEngine:
             pr.start()
         clean = False
         try:
+            if make_backend is not None:
+                t0 = time.perf_counter()
+                self.backend = make_backend()
+                self.stats['backend_init'] += time.perf_counter() - t0
             done = 0
             while done < n_procs:
                 t0 = time.perf_counter()
@@ -883,13 +888,15 @@ def stream_rank_main(moptions, rank: int, world: int, device: int, work, result_
     if world > 1:       # collectively, before any work: a rank that cannot join fails the run at once, not after its share of the reads
         rdv = dmcomm.FileRendezvous(os.path.join(moptions['outFolder'], '.rendezvous'), rank, world)
         communicator = dmcomm.Communicator.from_rendezvous(device, rdv)
-    backend = HipBackend(moptions, device)
+    use_procs = feeder_procs > 0 and hasattr(work, 'get')
+    backend = None if use_procs else HipBackend(moptions, device)       # with feeder processes: created once they are running
     eng = StreamEngine(moptions, backend, rank, world)
     if moptions.get('Ref') and os.path.isfile(moptions['Ref']):
         from . import readmap
         eng.set_reference_lengths({c: len(s) for c, s in readmap.read_fasta(moptions['Ref']).items()})
-    if feeder_procs > 0 and hasattr(work, 'get'):
-        eng.run_processes(work, feeder_procs, device)
+    if use_procs:
+        eng.run_processes(work, feeder_procs, device, make_backend=lambda: HipBackend(moptions, device))
+        backend = eng.backend
     else:
         batches = _drain(work) if hasattr(work, 'get') else iter(work)
         eng.run(batches, feeders=feeders, make_normalizer=lambda: dmsignal.SignalNormalizer(device))

@@ -87,3 +87,73 @@ def test_slot_ring_hand_over(tmp_path):
     assert got == ref and st['reads'] == st_ref['reads']
     assert st['slot_batches'] == len(items)                       # every batch went through a (recycled) slot
     assert not os.path.exists(stream.shm_dir_for(mo))
+
+
+def test_remote_signal_normalizer_protocol(tmp_path):
+    """The feeder side of the signal server (stream.RemoteSignalNormalizer: request layout, growth of the request file,
+    error channel), served here by a thread that answers from the signal oracle instead of the device."""
+    import mmap
+    import threading
+    from oracle import signal_oracle
+    from deepmod_amd import _lib, rawreads
+    requests, answers = queue.Queue(), queue.Queue()
+
+    def serve():
+        while True:
+            req = requests.get()
+            if req is None:
+                return
+            wid, path, size, n, n_raw, n_ev = req
+            with open(path, 'r+b') as fh:
+                mm = mmap.mmap(fh.fileno(), size)
+            o = stream._sig_layout(n, n_raw, n_ev)
+            raw = np.frombuffer(mm, np.int16, n_raw, o['raw'])
+            ro = np.frombuffer(mm, np.int64, n + 1, o['raw_off'])
+            eo = np.frombuffer(mm, np.int64, n + 1, o['ev_off'])
+            st = np.frombuffer(mm, np.uint64, n_ev, o['ev_start'])
+            ln = np.frombuffer(mm, np.uint64, n_ev, o['ev_length'])
+            if n_ev and int(ln[0]) == 0:
+                answers.put('bad request')
+                continue
+            for r in range(n):
+                ev = np.zeros(eo[r + 1] - eo[r], dtype=rawreads.EVENT_DTYPE)
+                ev['start'], ev['length'] = st[eo[r]:eo[r + 1]], ln[eo[r]:eo[r + 1]]
+                sig, norm = signal_oracle.mnormalized(raw[ro[r]:ro[r + 1]], ev)
+                mean, stdv, fe = signal_oracle.event_stats(sig, ev)
+                np.frombuffer(mm, np.float32, n_ev, o['mean'])[eo[r]:eo[r + 1]] = mean
+                np.frombuffer(mm, np.float32, n_ev, o['stdv'])[eo[r]:eo[r + 1]] = stdv
+                np.frombuffer(mm, np.float64, 6 * n, o['norm6'])[6 * r:6 * r + 6] = [norm[k] for k in ('mshift', 'mscale', 'read_med', 'read_mad', 'lower_lim', 'upper_lim')]
+                np.frombuffer(mm, np.int64, n, o['first_empty'])[r] = fe
+            answers.put(None)
+
+    th = threading.Thread(target=serve, daemon=True)
+    th.start()
+    rng = np.random.default_rng(4)
+    norm = stream.RemoteSignalNormalizer(0, str(tmp_path), requests, answers)
+    for n_reads, n_samples in ((3, 4000), (2, 700_000)):           # the second batch outgrows the first request file
+        reads = []
+        for _ in range(n_reads):
+            raw = rng.integers(300, 900, n_samples).astype(np.int16)
+            length = rng.integers(3, 12, n_samples // 10).astype(np.uint64)
+            start = np.concatenate([[5], 5 + np.cumsum(length)[:-1]]).astype(np.uint64)
+            reads.append((raw, start, length))
+        got = norm.event_stats_batch(reads)
+        assert len(got) == n_reads
+        for (raw, start, length), (mean, stdv, nd, fe) in zip(reads, got):
+            ev = np.zeros(len(start), dtype=rawreads.EVENT_DTYPE)
+            ev['start'], ev['length'] = start, length
+            sig, ref_norm = signal_oracle.mnormalized(raw, ev)
+            ref_mean, ref_stdv, ref_fe = signal_oracle.event_stats(sig, ev)
+            assert fe == ref_fe and np.array_equal(mean, ref_mean, equal_nan=True) and np.array_equal(stdv, ref_stdv, equal_nan=True)
+            assert nd['mshift'] == ref_norm['mshift'] and nd['upper_lim'] == ref_norm['upper_lim']
+    one = norm.event_stats(*reads[0])
+    assert np.array_equal(one[0], got[0][0], equal_nan=True) and one[4] is None
+    bad = (reads[0][0], reads[0][1], np.zeros_like(reads[0][2]))
+    try:
+        norm.event_stats_batch([bad])
+        raise AssertionError('the server error must surface')
+    except _lib.DeepModHipError as exc:
+        assert 'bad request' in str(exc)
+    requests.put(None)
+    th.join(timeout=5)
+    norm.close()

@@ -167,3 +167,41 @@ def test_batched_call_is_bit_identical_to_per_read_calls():
     assert isinstance(errs[2], _lib.DeepModHipError) and all(e is None for i, e in enumerate(errs) if i != 2)
     assert _same_f32(c[0]['m_event']['mean'], a[0]['m_event']['mean']) and _same_f32(c[5]['m_event']['stdv'], a[5]['m_event']['stdv'])
     nz.close()
+
+
+@pytest.mark.gpu
+def test_device_order_statistics_equal_host_order_statistics(monkeypatch):
+    """The batched call computes the four medians of every read on the device (signal_norm_batch_kernel); with
+    DEEPMOD_SIGNAL_HOST_NORM=1 it takes the host path (norm_from_hist).  Every median, limit, mean and stdv must agree bit for
+    bit on odd and even sample counts, narrow and wide value ranges, and on the reads that make the device path step aside
+    (a constant signal; more distinct values than the kernel compacts)."""
+    from deepmod_amd import signal
+    rng = np.random.default_rng(77)
+    cases = [_random_case(40 + i, n, ml) for i, (n, ml) in enumerate([(100_001, 9.0), (100_000, 9.0), (7_001, 4.0), (400_000, 30.0)])]
+    def events(n, mean_len):
+        length = np.maximum(1, rng.poisson(mean_len, max(2, int(n / mean_len) - 2))).astype(np.uint64)
+        start = np.concatenate([[3], 3 + np.cumsum(length)[:-1]]).astype(np.uint64)
+        keep = start + length <= n
+        return start[keep], length[keep]
+    narrow = rng.integers(500, 504, 50_000).astype(np.int16)                       # four distinct values
+    wide = rng.integers(-20_000, 20_000, 300_000).astype(np.int16)                 # ~40,000 distinct values: host path
+    constant = np.full(30_000, 612, np.int16)                                      # zero scale: host path (division by zero as numpy)
+    two = np.where(rng.random(40_001) < 0.5, 600, 601).astype(np.int16)            # medians between two bins
+    for arr in (narrow, wide, two):
+        cases.append((arr,) + events(len(arr), 8.0))
+    lists = {'plain': cases, 'with_constant': cases[:2] + [(constant,) + events(len(constant), 8.0)]}
+    for name, reads in lists.items():
+        monkeypatch.delenv('DEEPMOD_SIGNAL_HOST_NORM', raising=False)
+        dev = signal.SignalNormalizer(0)
+        monkeypatch.setenv('DEEPMOD_SIGNAL_HOST_NORM', '1')
+        host = signal.SignalNormalizer(0)
+        with np.errstate(all='ignore'):
+            a = dev.event_stats_batch(reads)
+            b = host.event_stats_batch(reads)
+        for i, ((m1, s1, n1, f1), (m2, s2, n2, f2)) in enumerate(zip(a, b)):
+            assert f1 == f2, (name, i)
+            for k in n1:
+                assert n1[k] == n2[k] or (np.isnan(n1[k]) and np.isnan(n2[k])), (name, i, k, n1[k], n2[k])
+            assert _same_f32(m1, m2) and _same_f32(s1, s2), (name, i)
+        dev.close()
+        host.close()

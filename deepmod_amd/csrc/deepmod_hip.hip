@@ -740,10 +740,10 @@ int model_init(dm_model* m, const float* weights) {
     HIP_TRY(hipMemcpy(m->d_hpack, P.h.data(), P.h.size() * sizeof(float), hipMemcpyHostToDevice));
     size_t scratch_bytes = size_t(m->grid_cap) * std::max(SCRATCH_FLOATS_PER_WG * sizeof(float), lstm16::SCRATCH_BYTES_PER_WG);
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
-    HIP_TRY(hipMemset(m->d_scratch, 0, scratch_bytes));
+    HIP_TRY(hipMemsetAsync(m->d_scratch, 0, scratch_bytes, m->stream));      // ordered with the launches of m->stream (non-blocking)
 #if defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2)
     HIP_TRY(hipMalloc(&m->d_dbg, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(m->d_dbg, 0, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(m->d_dbg, 0, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long), m->stream));
 #endif
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_f32_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_BYTES)));
@@ -1024,8 +1024,11 @@ dm_summary* dm_summary_create(int device, int64_t length) {
               hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc(&s->d_counts, sizeof(int) * 3 * length) == hipSuccess &&
               hipMalloc(&s->d_oob, sizeof(int)) == hipSuccess &&
-              hipMemset(s->d_counts, 0, sizeof(int) * 3 * length) == hipSuccess &&
-              hipMemset(s->d_oob, 0, sizeof(int)) == hipSuccess;
+              // on the summary's own (non-blocking) stream and waited for: a memset on the null stream is not ordered with the
+              // kernels that the summary's or a followed model's stream run next (3 GB of counters take a millisecond to clear)
+              hipMemsetAsync(s->d_counts, 0, sizeof(int) * 3 * length, s->stream) == hipSuccess &&
+              hipMemsetAsync(s->d_oob, 0, sizeof(int), s->stream) == hipSuccess &&
+              hipStreamSynchronize(s->stream) == hipSuccess;
     if (!ok) {
         fail(DM_EDEVICE, "summary allocation of %lld positions on device %d failed: %s", (long long)length, device,
              hipGetErrorString(hipGetLastError()));
@@ -1106,7 +1109,8 @@ static int summary_check_oob(dm_summary* s) {
     HIP_TRY(hipMemcpyAsync(&oob, s->d_oob, sizeof(int), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (oob) {
-        HIP_TRY(hipMemset(s->d_oob, 0, sizeof(int)));
+        HIP_TRY(hipMemsetAsync(s->d_oob, 0, sizeof(int), s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
         return fail(DM_EINVAL, "%d positions outside [0, %lld) were dropped", oob, (long long)s->length);
     }
     return DM_OK;

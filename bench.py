@@ -39,10 +39,6 @@ PRECISIONS = {
                            "by construction; back-to-back MFMAs on real operand bits sustain 1.4-1.6 PF on this part at its "
                            "1,400 W limit (profiles/r02/README.md)",
               "issued_per_algorithmic": 345 * 13 * 3 * 4 * 32768 * 2 / 128.0 / FLOP_PER_WINDOW},
-    "f16x3lm": {"peak": 2500.0, "kernel": "lstm16::bilstm_f16x3_kernel", "dtype": "f16x3",
-                "label": "split-f16 MFMA, layer-major kernel of round 1 (h sequence of a layer through a global scratch)",
-                "peak_note": "v_mfma_f32_16x16x32_f16; 3 products x 576/507 K padding = 3.41 matrix FLOP per algorithmic FLOP",
-                "issued_per_algorithmic": 3.0 * 576.0 / 507.0},
     "f32": {"peak": 157.3, "kernel": "lstm32::bilstm_f32_kernel", "dtype": "f32", "label": "fp32 MFMA",
             "peak_note": "v_mfma_f32_16x16x4_f32 dense fp32, 157.3 TF"},
 }
@@ -106,7 +102,7 @@ def cpu_baseline(weights, x_sample_src):
             "single_thread": {"value": one, "cores": 1, "sample": "%d windows in %.1f s" % (n_one, dt_one)}}
 
 
-KERNEL_SOURCES = {"f16x3": ["lstm_f16s.hip.inc"], "f16x3lm": ["lstm_f16.hip.inc"], "f32": ["lstm_f32.hip.inc"]}
+KERNEL_SOURCES = {"f16x3": ["lstm_f16s.hip.inc"], "f32": ["lstm_f32.hip.inc"]}
 
 
 def kernel_source_sha(precision):

@@ -15,8 +15,8 @@ DM_OPT_ASYNC = 3
 DM_OPT_RESERVED_CUS = 4
 DM_PREC_F32 = 0
 DM_PREC_F16X3 = 1
-DM_PREC_F16X3_LM = 2   # layer-major split-f16 kernel of round 1 (same arithmetic; the default is measured against it)
-DM_INFO_PRECISION, DM_INFO_F16_REPRESENTABLE, DM_INFO_F16_LENGTH_SHIFT, DM_INFO_DEVICE = 1, 2, 3, 4
+DM_PREC_F16X3_LM = 2   # layer-major split-f16 kernel of round 1: only in a library built with -DDM_WITH_F16X3_LM (DM_INFO_HAS_F16X3_LM)
+DM_INFO_PRECISION, DM_INFO_F16_REPRESENTABLE, DM_INFO_F16_LENGTH_SHIFT, DM_INFO_DEVICE, DM_INFO_HAS_F16X3_LM = 1, 2, 3, 4, 5
 DM_OK, DM_EINVAL, DM_EDEVICE, DM_ENOMEM, DM_ESTATE, DM_ERCCL, DM_ERANGE = 0, -1, -2, -3, -4, -5, -6
 (DM_MAP_STATUS, DM_MAP_N_ROWS, DM_MAP_LEFTCLIP, DM_MAP_RIGHTCLIP, DM_MAP_EV_LO, DM_MAP_EV_HI, DM_MAP_FIRST_MATCH_POS,
  DM_MAP_LAST_MATCH_POS, DM_MAP_NUM_INSERT, DM_MAP_NUM_DELETE, DM_MAP_NUM_MISMATCH, DM_MAP_STRAND, DM_MAP_POS_AFTER_CLIP,

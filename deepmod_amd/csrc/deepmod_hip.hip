@@ -16,9 +16,12 @@
 #include <vector>
 
 #include "../../include/deepmod_hip.h"
+#include "head.hip.inc"
 #include "lstm_f32.hip.inc"
-#include "lstm_f16.hip.inc"
 #include "lstm_f16s.hip.inc"
+#ifdef DM_WITH_F16X3_LM   // the layer-major split-f16 kernel of round 1: an experiment build, not part of the product
+#include "../../tools/experiments/f16lm/lstm_f16lm.hip.inc"
+#endif
 
 #ifdef DM_TRACE2
 #define DM16_TRACE2_LDS 2048
@@ -146,15 +149,16 @@ int choose_len_shift(const float* flat) {
     float m = 0.0f;
     const float* p = flat;
     for (int d = 0; d < 2; ++d) {
-        const float* row = p + size_t(lstm16::NFEAT - 1) * 400;            // layer-0 kernel row of feature 6
+        const float* row = p + size_t(lstmhead::NFEAT - 1) * 400;          // layer-0 kernel row of feature 6
         for (int gc = 0; gc < 400; ++gc) m = std::max(m, std::fabs(row[gc] * gate_scale(gc)));
-        p += size_t(lstm16::NFEAT + lstm16::HID) * 400 + 400 + 2 * (size_t(2 * lstm16::HID) * 400 + 400);
+        p += size_t(lstmhead::NFEAT + lstmhead::HID) * 400 + 400 + 2 * (size_t(2 * lstmhead::HID) * 400 + 400);
     }
     int k = 10;
     while (k > 0 && !(m * std::ldexp(1.0f, k) <= 32768.0f)) --k;
     return k;
 }
 
+#ifdef DM_WITH_F16X3_LM
 Packed16 pack_weights_f16(const float* flat) {
     using namespace lstm16;
     Packed16 P;
@@ -208,6 +212,8 @@ Packed16 pack_weights_f16(const float* flat) {
     }
     return P;
 }
+
+#endif  // DM_WITH_F16X3_LM
 
 // tile-major split-f16 packing (lstm_f16s.hip.inc): [dir][layer][tile][k16-step][hi|lo][lane][8 x f16].
 // A-operand lane l of record (tile T, k16-step t): gate row m = l % 32 -> unit 8T + m / 4, gate m % 4;
@@ -466,7 +472,7 @@ int ensure_plogit(dm_model* m, int64_t ntiles) {
     m->d_plogit = nullptr;
     m->plogit_tiles = 0;
     const int64_t cap = std::max<int64_t>(ntiles + ntiles / 4, 1024);
-    HIP_TRY(hipMalloc(&m->d_plogit, size_t(2) * size_t(cap) * lstm16::TILE_M * 2 * sizeof(float)));
+    HIP_TRY(hipMalloc(&m->d_plogit, size_t(2) * size_t(cap) * lstmhead::TILE_M * 2 * sizeof(float)));
     m->plogit_tiles = cap;
     return DM_OK;
 }
@@ -496,6 +502,7 @@ int ensure_f16s(dm_model* m) {
     return DM_OK;
 }
 
+#ifdef DM_WITH_F16X3_LM
 int ensure_f16lm(dm_model* m) {
     if (m->d_wpack16) return DM_OK;
     int rc = ensure_f16_common(m);
@@ -507,6 +514,8 @@ int ensure_f16lm(dm_model* m) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16::LDS_BYTES) + DM16_TRACE2_LDS));
     return DM_OK;
 }
+
+#endif
 
 // launch on device-resident buffers
 int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, float* d_prob, uint8_t* d_cls) {
@@ -550,9 +559,10 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         const int grid = std::min(2 * p.ntiles, m->grid_cap);
         hipLaunchKernelGGL(bilstm_f16s_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
         const long long npad = (long long)p.ntiles * TILE_M;
-        hipLaunchKernelGGL(lstm16::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
+        hipLaunchKernelGGL(lstmhead::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
                            npad, m->bout[0], m->bout[1], d_prob, d_cls);
     } else
+#ifdef DM_WITH_F16X3_LM
     if (m->precision == DM_PREC_F16X3_LM) {
         using namespace lstm16;
         int rc = ensure_f16lm(m);
@@ -583,10 +593,12 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         hipLaunchKernelGGL(bilstm_f16x3_kernel, dim3(grid), dim3(THREADS), LDS_BYTES + DM16_TRACE2_LDS, m->stream, p);
         if (p.dir_split) {
             const long long npad = (long long)p.ntiles * TILE_M;
-            hipLaunchKernelGGL(head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
+            hipLaunchKernelGGL(lstmhead::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
                                npad, m->bout[0], m->bout[1], d_prob, d_cls);
         }
-    } else {
+    } else
+#endif
+    {
         using namespace lstm32;
         Params p;
         p.wpack = m->d_wpack;
@@ -612,7 +624,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         hipLaunchKernelGGL(bilstm_f32_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
         if (p.dir_split) {
             const long long npad = (long long)p.ntiles * TILE_M;
-            hipLaunchKernelGGL(lstm16::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit,
+            hipLaunchKernelGGL(lstmhead::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit,
                                (long long)n, npad, m->bout[0], m->bout[1], d_prob, d_cls);
         }
     }
@@ -738,7 +750,10 @@ int model_init(dm_model* m, const float* weights) {
     HIP_TRY(hipMemcpy(m->d_wpack, P.w.data(), P.w.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_bpack, P.b.data(), P.b.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_hpack, P.h.data(), P.h.size() * sizeof(float), hipMemcpyHostToDevice));
-    size_t scratch_bytes = size_t(m->grid_cap) * std::max(SCRATCH_FLOATS_PER_WG * sizeof(float), lstm16::SCRATCH_BYTES_PER_WG);
+    size_t scratch_bytes = size_t(m->grid_cap) * SCRATCH_FLOATS_PER_WG * sizeof(float);      // h sequences of the fp32 kernel
+#ifdef DM_WITH_F16X3_LM
+    scratch_bytes = std::max(scratch_bytes, size_t(m->grid_cap) * lstm16::SCRATCH_BYTES_PER_WG);
+#endif
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
     HIP_TRY(hipMemsetAsync(m->d_scratch, 0, scratch_bytes, m->stream));      // ordered with the launches of m->stream (non-blocking)
 #if defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2)
@@ -854,6 +869,10 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
             return DM_OK;
         case DM_OPT_PRECISION:
             if (value != DM_PREC_F32 && value != DM_PREC_F16X3 && value != DM_PREC_F16X3_LM) return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
+#ifndef DM_WITH_F16X3_LM
+            if (value == DM_PREC_F16X3_LM)
+                return fail(DM_EINVAL, "DM_PREC_F16X3_LM (the layer-major kernel of round 1) is not part of this build; rebuild with -DDM_WITH_F16X3_LM");
+#endif
             if (value != DM_PREC_F32 && !m->f16_ok)
                 return fail(DM_EINVAL, "DM_PREC_F16X3 refused: a packed weight of this model is outside the f16 range (|w| x 2.886 > 65504)");
             m->precision = int(value);
@@ -904,6 +923,13 @@ int dm_model_get_info(dm_model* m, int key, int64_t* value) {
         case DM_INFO_F16_REPRESENTABLE: *value = m->f16_ok ? 1 : 0; return DM_OK;
         case DM_INFO_F16_LENGTH_SHIFT: *value = m->len_shift; return DM_OK;
         case DM_INFO_DEVICE: *value = m->device; return DM_OK;
+        case DM_INFO_HAS_F16X3_LM:
+#ifdef DM_WITH_F16X3_LM
+            *value = 1;
+#else
+            *value = 0;
+#endif
+            return DM_OK;
         default: return fail(DM_EINVAL, "unknown info key %d", key);
     }
 }

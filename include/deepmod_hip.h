@@ -75,13 +75,15 @@ extern "C" {
                                   An input outside these bounds (or NaN) makes the call fail with DM_ERANGE - synchronous
                                   calls on return, DM_OPT_ASYNC calls at the next dm_model_sync. */
 #define DM_PREC_F16X3_LM 2 /* the same arithmetic and range contract in the layer-major kernel of round 1
-                              (csrc/lstm_f16.hip.inc: the h sequence of a layer goes through a per-workgroup global scratch);
-                              ~10 % slower, kept selectable as the second implementation the default is measured against. */
+                              (tools/experiments/f16lm: the h sequence of a layer goes through a per-workgroup global scratch);
+                              ~10 % slower.  Not part of the product build: selectable only in a library built with
+                              -DDM_WITH_F16X3_LM (DM_INFO_HAS_F16X3_LM), otherwise refused with DM_EINVAL. */
 /* dm_model_get_info keys */
 #define DM_INFO_PRECISION 1          /* DM_PREC_* in effect */
 #define DM_INFO_F16_REPRESENTABLE 2  /* 1 if the weights fit DM_PREC_F16X3 */
 #define DM_INFO_F16_LENGTH_SHIFT 3   /* k above */
 #define DM_INFO_DEVICE 4
+#define DM_INFO_HAS_F16X3_LM 5       /* 1 if the library was built with the layer-major experiment kernel */
 
 typedef struct dm_model dm_model;
 typedef struct dm_summary dm_summary;

@@ -26,12 +26,12 @@ def _check(prob, cls, ref_prob, ref_cls):
     return err
 
 
-@pytest.fixture(scope="module", params=["f32", "f16x3", "f16x3lm"])
+@pytest.fixture(scope="module", params=["f32", "f16x3"])
 def models(gpu_device, request):
     """Every parity test runs for both precision modes of the library: exact-fp32 MFMA and the split-f16
     (3 products per fp32 product) MFMA path.  Same tolerance for both."""
     from deepmod_amd import _lib
-    prec = {"f32": _lib.DM_PREC_F32, "f16x3": _lib.DM_PREC_F16X3, "f16x3lm": _lib.DM_PREC_F16X3_LM}[request.param]
+    prec = {"f32": _lib.DM_PREC_F32, "f16x3": _lib.DM_PREC_F16X3}[request.param]
     cache = {}
 
     def get(seed, scale):
@@ -279,9 +279,29 @@ def test_session_adapter_matches_reference_call_forms(models, tmp_path, gpu_devi
     sess.close()
 
 
+def test_layer_major_experiment_kernel_is_refused_or_agrees(gpu_device):
+    """DM_PREC_F16X3_LM (tools/experiments/f16lm) is not part of the product build: the library refuses it unless it was
+    built with -DDM_WITH_F16X3_LM, in which case it has to pass the same parity check as the product kernels."""
+    from deepmod_amd import _lib
+    w = synth.synthetic_weights(26, 4.0)
+    x = synth.synthetic_windows(1000, seed=12)
+    m = model.BiLSTMModel(w, device=gpu_device)
+    if not m.get_info(_lib.DM_INFO_HAS_F16X3_LM):
+        with pytest.raises(_lib.DeepModHipError):
+            m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3_LM)
+        assert m.get_info(_lib.DM_INFO_PRECISION) == _lib.DM_PREC_F16X3
+    else:
+        m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3_LM)
+        prob, cls = m.predict_windows(x)
+        _check(prob, cls, *oracle_np.predict_windows_c(w, x))
+    m.close()
+
+
 def test_bench_distributed_path_single_rank(gpu_device):
-    """The N > 1 code path of bench.py (torch.distributed nccl init, per-rank device, the counter
-    all-reduce through the aliased torch tensor, MAX-reduced timing) exercised with one rank."""
+    """The N > 1 code path of bench.py exercised with one rank (DM_BENCH_FORCE_DIST=1 under torch.distributed.run, which is
+    only the launcher): file rendezvous, ONE persistent RCCL communicator created through the C ABI (dm_comm_create), the
+    per-position counters merged with dm_summary_reduce_scatter inside the timed region, barrier and max-over-ranks of the
+    elapsed time through the same communicator."""
     import json
     import os
     import subprocess
@@ -297,6 +317,11 @@ def test_bench_distributed_path_single_rank(gpu_device):
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["config"]["forced_dist_dry_run"] is True
     assert out["value"] > 1e6 and out["summary_check"]["touch"] > 0
+    mg = out["multi_gpu"]
+    assert mg["rccl_nranks"] == 1
+    assert mg["collectives"] == 2                      # one untimed warm-up merge of the same size + the timed one
+    assert mg["bytes"] == 2 * 12 * 4_641_652           # touch | cov | mod, int32, both times
+    assert "ncclReduceScatter" in mg["collective"] or "ncclReduce" in mg["collective"]
 
 
 def test_batched_reads_equal_per_read_calls(models, tmp_path, gpu_device):

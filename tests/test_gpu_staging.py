@@ -65,7 +65,7 @@ def test_reserved_cus_do_not_change_results(gpu_device):
     """DM_OPT_RESERVED_CUS shrinks the persistent grid of every classifier kernel; results are those of the full grid."""
     w = synth.synthetic_weights(26, 4.0)
     x = synth.synthetic_windows(70000, seed=9)             # more work items than workgroups for every kernel
-    for prec in ("f16x3", "f16x3lm", "f32"):
+    for prec in ("f16x3", "f32"):
         m = model.BiLSTMModel(w, device=gpu_device, precision=prec)
         p0, c0 = m.predict_windows(x)
         m.set_option(_lib.DM_OPT_RESERVED_CUS, 32)

@@ -11,12 +11,8 @@ bash tools/profile_round.sh ${RND}_f16x3 f16x3 > $O/profile.log 2>&1
 python tools/summarize_profiles.py ${RND}_f16x3 $O/prof_f16x3 > /dev/null
 bash tools/profile_round.sh ${RND}_f32 f32 >> $O/profile.log 2>&1
 python tools/summarize_profiles.py ${RND}_f32 $O/prof_f32 > /dev/null
-python bench.py --precision f16x3lm --no-cpu-baseline > $O/bench_f16x3lm.json 2>/dev/null
-bash tools/profile_round.sh ${RND}_f16x3lm f16x3lm >> $O/profile.log 2>&1
-python tools/summarize_profiles.py ${RND}_f16x3lm $O/prof_f16x3lm > /dev/null
 ( python tools/e2e_rate.py packed 200 | sed -n 2,2p; python tools/e2e_rate.py raw 60 | sed -n 2,2p; python tools/e2e_rate.py feat 60 | sed -n 2,2p ) > $O/e2e_rate.txt 2>&1
 python tools/e2e_detect_raw.py 12000 16 > $O/e2e_detect_raw.txt 2>&1
 bash tools/power_trace.sh $O/power_f16x3.txt python tools/bench_loop.py f16x3 6 > /dev/null
-bash tools/power_trace.sh $O/power_f16x3lm.txt python tools/bench_loop.py f16x3lm 6 > /dev/null
 bash tools/power_trace.sh $O/power_f32.txt python tools/bench_loop.py f32 6 > /dev/null
 tail -c 300 $O/bench_f16x3.json; echo; cat $O/e2e_rate.txt

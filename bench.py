@@ -30,7 +30,7 @@ N_BATCHES = 16                # 16 x 65,536 = 1,048,576 windows ("10^6 windows b
 FLOP_PER_WINDOW = 8.924e6     # 11 live steps x 2 dirs x 3 layers + head
 # /opt/skills/guides/MI355X_MICROARCH.md dense MFMA peaks: v_mfma_f32_16x16x4_f32 157.3 TF, 16-bit (f16/bf16) 2.5 PF
 PRECISIONS = {
-    "f16x3": {"peak": 2500.0, "kernel": "lstm16s::bilstm_f16s_kernel", "dtype": "f16x3",
+    "f16x3": {"peak": 2500.0, "kernel": "lstm16s::bilstm_f16s_kernel<0>", "dtype": "f16x3",
               "label": "split-f16 MFMA (hi+lo f16 operands, 3 products per fp32 product, fp32 accumulate), step-major: "
                        "the state of all three layers stays on the chip",
               "peak_note": "v_mfma_f32_32x32x16_f16 dense 16-bit peak 2.5 PF; the kernel issues 345 k16-steps x 13 tiles x 3 products of "
@@ -39,6 +39,13 @@ PRECISIONS = {
                            "by construction; back-to-back MFMAs on real operand bits sustain 1.4-1.6 PF on this part at its "
                            "1,400 W limit (profiles/r02/README.md)",
               "issued_per_algorithmic": 345 * 13 * 3 * 4 * 32768 * 2 / 128.0 / FLOP_PER_WINDOW},
+    "f16i8": {"peak": 2500.0, "kernel": "lstm16s::bilstm_f16s_kernel<1>", "dtype": "f16+i8",
+              "label": "OPT-IN: split-f16 MFMA with both cross terms of every product as one int8 MFMA (v_mfma_i32_32x32x32_i8, int32 "
+                       "accumulate, folded per tile); max |dp| 3-6e-5 at weight scale 4 instead of 3e-6",
+              "peak_note": "priced against the dense 16-bit peak 2.5 PF like the default: per 32 windows and direction the kernel issues 701 "
+                           "MFMA units of 32 cycles per output tile instead of 1,035 (layer 0's feature k16-step keeps three f16 products) = "
+                           "2.09 matrix units per algorithmic unit",
+              "issued_per_algorithmic": 701 * 13 * 4 * 32768 * 2 / 128.0 / FLOP_PER_WINDOW},
     "f32": {"peak": 157.3, "kernel": "lstm32::bilstm_f32_kernel", "dtype": "f32", "label": "fp32 MFMA",
             "peak_note": "v_mfma_f32_16x16x4_f32 dense fp32, 157.3 TF"},
 }
@@ -90,11 +97,12 @@ def cpu_baseline(weights, x_sample_src):
     oracle_np.build_c_oracle()
     run = lambda x, t: (lambda: oracle_np.predict_windows_c(weights, x, nthreads=t))
     sample = x_sample_src[:16384]
+    ref_prob, ref_cls = oracle_np.predict_windows_c(weights, sample, nthreads=cores)     # kept: bench's parity field compares the GPU path with it
     big, n_big, dt_big = _timed(run(sample, cores), len(sample), 12.0)
     chunks = [sample[i:i + 512] for i in range(0, 4096, 512)]
     b512, n512, dt512 = _timed(lambda: [oracle_np.predict_windows_c(weights, c, nthreads=cores) for c in chunks], 4096, 6.0)
     one, n_one, dt_one = _timed(run(sample[:1024], 1), 1024, 6.0)
-    return {"value": big, "unit": "base-positions/s", "cores": cores, "cores_why": why, "logical_cpus": os.cpu_count(), "kind": "port",
+    return (ref_prob, ref_cls), {"value": big, "unit": "base-positions/s", "cores": cores, "cores_why": why, "logical_cpus": os.cpu_count(), "kind": "port",
             "sample": "%d windows (passes over the first 16,384 windows of batch 0) in %.1f s, oracle/deepmod_oracle.c = fp32 C "
                       "restatement of the TF graph with libm expf/tanhf (scalar-ish loop nest, ~0.4 TFLOP/s; NOT TensorFlow/Eigen), "
                       "%d OpenMP threads" % (n_big, dt_big, cores),
@@ -102,7 +110,7 @@ def cpu_baseline(weights, x_sample_src):
             "single_thread": {"value": one, "cores": 1, "sample": "%d windows in %.1f s" % (n_one, dt_one)}}
 
 
-KERNEL_SOURCES = {"f16x3": ["lstm_f16s.hip.inc"], "f32": ["lstm_f32.hip.inc"]}
+KERNEL_SOURCES = {"f16x3": ["lstm_f16s.hip.inc"], "f16i8": ["lstm_f16s.hip.inc"], "f32": ["lstm_f32.hip.inc"]}
 
 
 def kernel_source_sha(precision):
@@ -160,25 +168,51 @@ def power_evidence(precision):
     return None
 
 
+def parity_field(m, x_sample, ref):
+    """max |dp|, class flips away from near ties and AUC of the GPU path's p1 against the oracle's class on the windows the
+    cpu_baseline leg classified with the oracle (BASELINE.json: the metric is base-positions/s + per-base AUC vs ref)."""
+    ref_prob, ref_cls = ref
+    prob, cls = m.predict_windows(x_sample)
+    near = np.abs(ref_prob[:, 1] - 0.5) < 1e-4
+    clear = ~near
+    pos, neg = prob[clear & (ref_cls == 1), 1], prob[clear & (ref_cls == 0), 1]
+    auc = None
+    if len(pos) and len(neg):         # Mann-Whitney U with midranks
+        allv = np.concatenate([pos, neg]).astype(np.float64)
+        order = np.argsort(allv, kind="mergesort")
+        ranks = np.empty(len(allv))
+        ranks[order] = np.arange(1, len(allv) + 1)
+        sv = allv[order]
+        lo = np.searchsorted(sv, sv, "left")
+        hi = np.searchsorted(sv, sv, "right")
+        ranks[order] = 0.5 * (lo + hi + 1)
+        auc = float((ranks[:len(pos)].sum() - len(pos) * (len(pos) + 1) / 2.0) / (len(pos) * len(neg)))
+    return {"windows": int(len(x_sample)), "max_abs_dp": float(np.abs(prob - ref_prob).max()), "tolerance": 1e-4,
+            "class_flips": int(((cls.astype(np.int64) != ref_cls) & clear).sum()), "near_ties": int(near.sum()),
+            "auc_vs_oracle": auc, "class1_fraction_oracle": float(ref_cls.mean()),
+            "note": "GPU path vs oracle/deepmod_oracle.c on the first 16,384 windows of batch 0 (untimed); AUC of p1 against the oracle's class away from near ties"}
+
+
 def extras(m, _lib, model, precision, x_dev0, x_host0, prob_dev, cls_dev, reps=4):
-    """Untimed-for-`value` side measurements on rank 0 at N = 1: the other MFMA mode on the same batch (kernel
+    """Untimed-for-`value` side measurements on rank 0 at N = 1: the other MFMA modes on the same batch (kernel
     time from HIP events) and the PCIe-inclusive rate when the boundary is handed pageable host buffers."""
     out = {}
     m.set_option(_lib.DM_OPT_ASYNC, 0)
-    other = "f32" if precision.startswith("f16x3") else "f16x3"
-    m.set_precision(other)
-    m.predict_windows(x_dev0, prob=prob_dev, cls=cls_dev)
-    m.sync()
-    m.profile_reset()
-    for _ in range(reps):
+    for key, other in (("other_precision", "f32" if precision.startswith("f16") else "f16x3"),
+                       ("opt_in_precision", "f16i8" if precision != "f16i8" else "f16x3")):
+        m.set_precision(other)
         m.predict_windows(x_dev0, prob=prob_dev, cls=cls_dev)
-    m.sync()
-    ms, launches, kw = m.profile_get()
-    rate = kw / (ms * 1e-3)
-    Q = PRECISIONS[other]
-    out["other_precision"] = {"precision": other, "kernel": Q["kernel"], "avg_launch_ms": ms / max(launches, 1),
-                              "windows_per_s_kernel": rate, "achieved_tflops": rate * FLOP_PER_WINDOW / 1e12,
-                              "peak_tflops": Q["peak"], "frac": rate * FLOP_PER_WINDOW / 1e12 / Q["peak"]}
+        m.sync()
+        m.profile_reset()
+        for _ in range(reps if other == "f32" else 4 * reps):
+            m.predict_windows(x_dev0, prob=prob_dev, cls=cls_dev)
+        m.sync()
+        ms, launches, kw = m.profile_get()
+        rate = kw / (ms * 1e-3)
+        Q = PRECISIONS[other]
+        out[key] = {"precision": other, "kernel": Q["kernel"], "avg_launch_ms": ms / max(launches, 1),
+                    "windows_per_s_kernel": rate, "achieved_tflops": rate * FLOP_PER_WINDOW / 1e12,
+                    "peak_tflops": Q["peak"], "frac": rate * FLOP_PER_WINDOW / 1e12 / Q["peak"], "label": Q["label"]}
     m.set_precision(precision)
     m.predict_windows(x_host0)            # host in, host out: H2D + kernel + D2H, synchronous
     t0 = time.perf_counter()
@@ -348,7 +382,9 @@ def main():
         if world == 1 and not args.no_extras:
             out["extras"] = extras(m, _lib, model, args.precision, x_dev[0], x0, prob_dev, cls_dev)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(weights, x0)
+            ref, out["cpu_baseline"] = cpu_baseline(weights, x0)
+            m.set_option(_lib.DM_OPT_ASYNC, 0)
+            out["parity"] = parity_field(m, x0[:16384], ref)
         try:      # RCCL prints its version banner through C stdio: push it out first so that the JSON line is the last line
             import ctypes
             ctypes.CDLL(None).fflush(None)

@@ -222,7 +222,14 @@ Packed16 pack_weights_f16(const float* flat) {
 //   t == 6: j < 4: own unit 96 + 2j + half (slot 100 = the constant 1.0 -> bias row; 101..103 zero);
 //           j >= 4: layer 0: feature 2 (j-4) + half (7 = event length x 2^-len_shift); layers 1, 2: input unit 96 + 2 (j-4) + half
 //   t > 6 : input unit 8 (2 (t-7) + j/4) + 2 (j%4) + half
-Packed16 pack_weights_tile(const float* flat) {
+// int8 = true (DM_PREC_F16I8): the second KB of a record holds, instead of the lo f16 halves, the int8 cross-term weights of the
+// same 16 K slots: bytes (2j, 2j + 1) of lane l = (w_hi8, w_lo8) of the unit of slot j - they meet the B bytes (lo8, hi8) of that
+// unit in one v_mfma_i32_32x32x32_i8.  Scales, per (direction, layer, gate kind g): sw = max(|w_hi|, 2^12 |w_lo|) over the gate's
+// rows; w_hi8 = rint(127 w_hi / sw), w_lo8 = rint(127 * 2^12 w_lo / sw); with lo8 = rint(127 * 2^12 h_lo) and hi8 = rint(127 h) one
+// count of the int32 accumulator is i8s = sw 2^-12 / 127^2 pre-activation units for both slots.  Layer 0's mixed k16-step
+// (t = 6: own units 96..99, bias slot, RAW features) keeps its f16 lo record: the kernel runs it with three f16 products.
+// (An int32 accumulator cannot overflow: 2 * 208 slots * 127 * 127 < 2^23.)
+Packed16 pack_weights_tile(const float* flat, const bool int8 = false, float* i8s = nullptr) {
     using namespace lstm16s;
     Packed16 P;
     P.w.assign(WEIGHT_BYTES, 0);
@@ -237,9 +244,49 @@ Packed16 pack_weights_tile(const float* flat) {
             const float* kern = p;
             const float* bias = p + size_t(kin + HID) * 400;
             p += size_t(kin + HID) * 400 + 400;
+            float sw[4] = {0.f, 0.f, 0.f, 0.f};
+            constexpr float MAGIC = 0.0f;     // (a bias-row offset for accumulators that would not start from 0: none)
+            // value of (TF kernel row krow | bias row = kin + HID, gate column gc) as the int8 pack stores it
+            auto packed_value = [&](int krow, int gc, const float* swp) {
+                if (krow < kin + HID) return kern[size_t(krow) * 400 + gc] * gate_scale(gc);
+                return (bias[gc] + (gc / 100 == 2 ? 1.0f : 0.0f)) * gate_scale(gc) - (int8 ? swp[gc / 100] / (4096.0f * 127.0f * 127.0f) * MAGIC : 0.0f);
+            };
+            if (int8) {      // every value that rides the int8 product: the recurrent rows, layers 1, 2 also the input rows, the bias row
+                for (int gk = 0; gk < 4; ++gk) {
+                    float m = 0.0f;
+                    for (int u = 0; u < HID; ++u)
+                        for (int krow = (l == 0 ? NFEAT : 0); krow <= kin + HID; ++krow) {
+                            const float v = packed_value(krow, gk * 100 + u, sw);     // (bias offset of sw = 0: the loop below settles it)
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)(v - (float)hi);
+                            m = std::max(m, std::max(std::fabs((float)hi), 4096.0f * std::fabs((float)lo)));
+                        }
+                    sw[gk] = m > 0.0f ? m : 1.0f;
+                    for (int tries = 0; tries < 64; ++tries) {        // representable with this sw, and no row can leave (-2^22, 2^22)?
+                        bool ok = true;
+                        for (int u = 0; u < HID && ok; ++u) {
+                            double worst = 0.0;
+                            for (int krow = (l == 0 ? NFEAT : 0); krow <= kin + HID; ++krow) {
+                                const float v = packed_value(krow, gk * 100 + u, sw);
+                                const _Float16 hi = (_Float16)v;
+                                const _Float16 lo = (_Float16)(v - (float)hi);
+                                const float qh = std::fabs((float)hi) * 127.0f / sw[gk], ql = std::fabs((float)lo) * 4096.0f * 127.0f / sw[gk];
+                                if (qh > 127.0f || ql > 127.0f) ok = false;
+                                worst += 127.0 * (std::nearbyint(std::min(qh, 127.0f)) + std::nearbyint(std::min(ql, 127.0f)));
+                            }
+                            (void)worst;
+                        }
+                        if (ok) break;
+                        sw[gk] *= 1.125f;
+                    }
+                    if (i8s) i8s[(d * 3 + l) * 4 + gk] = sw[gk] / (4096.0f * 127.0f * 127.0f);
+                }
+            }
             for (int T = 0; T < NTILE; ++T)
                 for (int t = 0; t < nks; ++t) {
                     _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + off);
+                    signed char* dst8 = reinterpret_cast<signed char*>(P.w.data() + off + REC_BYTES / 2);
+                    const bool rec8 = int8 && !(l == 0 && t == 6);
                     off += REC_BYTES;
                     for (int lane = 0; lane < 64; ++lane) {
                         const int m = lane & 31, half = lane >> 5;
@@ -267,16 +314,21 @@ Packed16 pack_weights_tile(const float* flat) {
                                     const int u = 8 * (2 * (t - 7) + j / 4) + 2 * (j % 4) + half;
                                     if (u < HID) krow = u;
                                 }
-                                if (krow >= 0) v = kern[size_t(krow) * 400 + gc];
-                                else if (krow == -2) v = bias[gc] + (gate == 2 ? 1.0f : 0.0f);   // + forget_bias
-                                v *= gate_scale(gc) * mul;
+                                if (krow >= 0) v = kern[size_t(krow) * 400 + gc] * gate_scale(gc) * mul;
+                                else if (krow == -2) v = packed_value(kin + HID, gc, sw);        // bias + forget_bias (int8 pack: - i8s * MAGIC)
                             }
                             if (!std::isfinite(v)) P.finite = false;
                             else P.max_abs = std::max(P.max_abs, std::fabs(v));
                             const _Float16 hi = (_Float16)v;
                             const _Float16 lo = (_Float16)(v - (float)hi);
                             dst[(0 * 64 + lane) * 8 + j] = hi;
-                            dst[(1 * 64 + lane) * 8 + j] = lo;
+                            if (!rec8) dst[(1 * 64 + lane) * 8 + j] = lo;
+                            else {
+                                const float s8 = 127.0f / sw[gate];
+                                const float qh = std::nearbyint((float)hi * s8), ql = std::nearbyint((float)lo * s8 * 4096.0f);
+                                dst8[lane * 16 + 2 * j] = (signed char)std::max(-127.0f, std::min(127.0f, qh));
+                                dst8[lane * 16 + 2 * j + 1] = (signed char)std::max(-127.0f, std::min(127.0f, ql));
+                            }
                         }
                     }
                 }
@@ -392,6 +444,8 @@ struct dm_model {
     float* d_hpack = nullptr;
     unsigned char* d_wpack16 = nullptr;   // split-f16 weights in the layer-major kernel's layout (DM_PREC_F16X3_LM)
     unsigned char* d_wpack16s = nullptr;  // split-f16 weights in the tile-major layout (DM_PREC_F16X3)
+    unsigned char* d_wpack16i = nullptr;  // the same layout with int8 cross-term records (DM_PREC_F16I8)
+    float i8s[24] = {};                   // its fold scales [dir][layer][gate kind]
     float* d_wout = nullptr;              // head W[200][2] fp32 (DM_PREC_F16X3)
     float* d_scratch = nullptr;
     unsigned long long* d_dbg = nullptr;  // DM_TIMING builds only
@@ -497,7 +551,19 @@ int ensure_f16s(dm_model* m) {
     Packed16 P = pack_weights_tile(m->host_weights.data());
     HIP_TRY(hipMalloc(&m->d_wpack16s, P.w.size()));
     HIP_TRY(hipMemcpy(m->d_wpack16s, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16s::bilstm_f16s_kernel),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16s::bilstm_f16s_kernel<0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16s::LDS_BYTES)));
+    return DM_OK;
+}
+
+int ensure_f16i8(dm_model* m) {
+    if (m->d_wpack16i) return DM_OK;
+    int rc = ensure_f16_common(m);
+    if (rc) return rc;
+    Packed16 P = pack_weights_tile(m->host_weights.data(), true, m->i8s);
+    HIP_TRY(hipMalloc(&m->d_wpack16i, P.w.size()));
+    HIP_TRY(hipMemcpy(m->d_wpack16i, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16s::bilstm_f16s_kernel<1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16s::LDS_BYTES)));
     return DM_OK;
 }
@@ -538,12 +604,15 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         ++m->events_used;
         HIP_TRY(hipEventRecord(e0, m->stream));
     }
-    if (m->precision == DM_PREC_F16X3) {
+    if (m->precision == DM_PREC_F16X3 || m->precision == DM_PREC_F16I8) {
         using namespace lstm16s;
-        int rc = ensure_f16s(m);
+        const bool i8 = m->precision == DM_PREC_F16I8;
+        int rc = i8 ? ensure_f16i8(m) : ensure_f16s(m);
         if (rc) return rc;
         Params p;
         p.wpack = m->d_wpack16s;
+        p.wpack_i8 = m->d_wpack16i;
+        for (int k = 0; k < 24; ++k) p.i8s[k] = m->i8s[k];
         p.hpack = m->d_wout;
         p.bout0 = m->bout[0];
         p.bout1 = m->bout[1];
@@ -557,7 +626,8 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         p.len_scale = std::ldexp(1.0f, -m->len_shift);
         p.range_flag = m->d_range_flag;
         const int grid = std::min(2 * p.ntiles, m->grid_cap);
-        hipLaunchKernelGGL(bilstm_f16s_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
+        if (i8) hipLaunchKernelGGL(bilstm_f16s_kernel<1>, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
+        else hipLaunchKernelGGL(bilstm_f16s_kernel<0>, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
         const long long npad = (long long)p.ntiles * TILE_M;
         hipLaunchKernelGGL(lstmhead::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
                            npad, m->bout[0], m->bout[1], d_prob, d_cls);
@@ -841,6 +911,7 @@ void dm_model_destroy(dm_model* m) {
     (void)hipFree(m->d_scratch);
     (void)hipFree(m->d_wpack16);
     (void)hipFree(m->d_wpack16s);
+    (void)hipFree(m->d_wpack16i);
     (void)hipFree(m->d_wout);
     (void)hipFree(m->d_dbg);
     (void)hipFree(m->d_plogit);
@@ -868,7 +939,8 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
             m->grid_cap = m->num_cu - int(value);
             return DM_OK;
         case DM_OPT_PRECISION:
-            if (value != DM_PREC_F32 && value != DM_PREC_F16X3 && value != DM_PREC_F16X3_LM) return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
+            if (value != DM_PREC_F32 && value != DM_PREC_F16X3 && value != DM_PREC_F16X3_LM && value != DM_PREC_F16I8)
+                return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
 #ifndef DM_WITH_F16X3_LM
             if (value == DM_PREC_F16X3_LM)
                 return fail(DM_EINVAL, "DM_PREC_F16X3_LM (the layer-major kernel of round 1) is not part of this build; rebuild with -DDM_WITH_F16X3_LM");

@@ -78,6 +78,12 @@ extern "C" {
                               (tools/experiments/f16lm: the h sequence of a layer goes through a per-workgroup global scratch);
                               ~10 % slower.  Not part of the product build: selectable only in a library built with
                               -DDM_WITH_F16X3_LM (DM_INFO_HAS_F16X3_LM), otherwise refused with DM_EINVAL. */
+#define DM_PREC_F16I8 3    /* OPT-IN: the step-major kernel with hi*hi in f16 and BOTH cross terms of every product as one int8 MFMA
+                              (v_mfma_i32_32x32x32_i8, int32 accumulation, folded into the fp32 pre-activations per tile): 2 issued
+                              matrix units per product instead of 3, ~19 % less time per window.  Operands carry ~19 bits instead
+                              of 22: max |dp| vs the fp32 graph 3-5e-5 at weight scale 4 (DM_PREC_F16X3: 3e-6; tolerance of the
+                              path: 1e-4), classes equal away from near ties.  Same range contract as DM_PREC_F16X3 (the raw
+                              features never ride the int8 product).  Never selected by default. */
 /* dm_model_get_info keys */
 #define DM_INFO_PRECISION 1          /* DM_PREC_* in effect */
 #define DM_INFO_F16_REPRESENTABLE 2  /* 1 if the weights fit DM_PREC_F16X3 */

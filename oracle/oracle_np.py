@@ -32,31 +32,35 @@ def _sigmoid(x):
     return (np.float32(1) / (np.float32(1) + np.exp(-x, dtype=np.float32))).astype(np.float32)
 
 
-def predict_windows_np(weights: Dict[str, np.ndarray], x: np.ndarray
+def predict_windows_np(weights: Dict[str, np.ndarray], x: np.ndarray, dtype=np.float32
                        ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """fp32 numpy restatement. x: [n,21,7] -> (prob [n,2] f32, cls [n] int64, hcat [n,200])."""
-    x = np.asarray(x, dtype=np.float32)
+    """numpy restatement, fp32 like the graph (default) or with every operation in `dtype` = float64: the EXACT value of
+    the graph on the fp32 weights and inputs, the yardstick where fp32 round-off itself is amplified (weight scale 16).
+    x: [n,21,7] -> (prob [n,2], cls [n] int64, hcat [n,200])."""
+    F = np.dtype(dtype).type
+    sig = lambda t: (F(1) / (F(1) + np.exp(-t, dtype=F))).astype(F)
+    x = np.asarray(x, dtype=np.float32).astype(F)
     n = x.shape[0]
     finals = []
     for d, direction in enumerate(("fw", "bw")):
-        h = [np.zeros((n, HID), np.float32) for _ in range(3)]
-        c = [np.zeros((n, HID), np.float32) for _ in range(3)]
+        h = [np.zeros((n, HID), F) for _ in range(3)]
+        c = [np.zeros((n, HID), F) for _ in range(3)]
         for s in range(LIVE):
             row = s if d == 0 else WIN - 1 - s
             inp = x[:, row, :]
             for l in range(3):
-                kern = weights[cell_name(direction, l, "kernel")].astype(np.float32)
-                bias = weights[cell_name(direction, l, "bias")].astype(np.float32)
-                g = (np.concatenate([inp, h[l]], axis=1) @ kern).astype(np.float32) + bias
+                kern = weights[cell_name(direction, l, "kernel")].astype(F)
+                bias = weights[cell_name(direction, l, "bias")].astype(F)
+                g = (np.concatenate([inp, h[l]], axis=1) @ kern).astype(F) + bias
                 gi, gj, gf, go = np.split(g, 4, axis=1)
-                c[l] = (c[l] * _sigmoid(gf + np.float32(1.0)) + _sigmoid(gi) * np.tanh(gj)).astype(np.float32)
-                h[l] = (np.tanh(c[l]) * _sigmoid(go)).astype(np.float32)
+                c[l] = (c[l] * sig(gf + F(1.0)) + sig(gi) * np.tanh(gj)).astype(F)
+                h[l] = (np.tanh(c[l]) * sig(go)).astype(F)
                 inp = h[l]
         finals.append(h[2])
     hcat = np.concatenate(finals, axis=1)
-    logits = (hcat @ weights[HEAD_W].astype(np.float32)).astype(np.float32) + weights[HEAD_B].astype(np.float32)
+    logits = (hcat @ weights[HEAD_W].astype(F)).astype(F) + weights[HEAD_B].astype(F)
     e = np.exp(logits - logits.max(axis=1, keepdims=True))
-    prob = (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+    prob = (e / e.sum(axis=1, keepdims=True)).astype(F)
     cls = np.argmax(prob, axis=1).astype(np.int64)
     return prob, cls, hcat
 

@@ -7,9 +7,10 @@ A "step" is one pass of the hot path over one batch of 65,536 synthetic 7-featur
 that are already resident in HBM: dm_predict_windows (BiLSTM classify) + dm_summary_add (per-position
 coverage / mod-count accumulate).  N > 1 (launched by torch.distributed.run, one rank per GPU; torch is only the
 launcher): windows shard across ranks with no data-path collective (weak scaling: every rank runs its own K
-batches); the only collective is ONE integer RCCL reduce of the per-position counters into rank 0 at the end,
-inside the timed region, through the product's C ABI (dm_comm_create once, dm_summary_reduce) - barriers and the
-max-over-ranks of the elapsed time go through the same communicator.  Rank 0 prints ONE JSON line.
+batches); the only collective is ONE integer RCCL reduce-scatter of the per-position counters at the end (every rank is
+left with the all-rank sums of its slice of the contig - the merge the streaming detect uses), inside the timed region,
+through the product's C ABI (dm_comm_create once, dm_summary_reduce_scatter) - barriers and the max-over-ranks of the
+elapsed time go through the same communicator.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -322,7 +323,7 @@ def main():
         # untimed, part of the warm-up: the first reduce of this size makes RCCL set up its channels and buffers
         warm = summary.PositionSummary(CONTIG_LEN, device=device)
         warm.follow(m)
-        warm.reduce(communicator, 0)
+        warm.reduce_scatter(communicator)
         warm.sync()
         warm.close()
     sync_all()
@@ -334,7 +335,7 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     if communicator is not None:
-        summ.reduce(communicator, 0)          # the only collective: int32 touch|cov|mod summed into rank 0 (ncclReduce)
+        summ.reduce_scatter(communicator)     # the only collective: int32 touch|cov|mod summed over the ranks, one slice per rank (ncclReduceScatter)
     sync_all()
     if communicator is not None:
         communicator.barrier()
@@ -342,8 +343,10 @@ def main():
     elapsed = communicator.max(elapsed_rank) if communicator is not None else elapsed_rank
     per_rank = None
     if communicator is not None:
+        sl = summ.fetch_slice()               # this rank's slice of the merged counters
         per_rank = rdv.all_gather_json("rate", {"rank": rank, "windows_per_s": BATCH * args.steps / elapsed_rank,
-                                                "elapsed_s": elapsed_rank, "device": device})
+                                                "elapsed_s": elapsed_rank, "device": device, "slice_first": summ._slice[0],
+                                                "slice_count": summ._slice[1], "slice_sums": [int(a.sum()) for a in sl]})
 
     kernel_ms, launches, kwindows = m.profile_get()
     total_windows = BATCH * args.steps * world
@@ -352,7 +355,10 @@ def main():
     if rank == 0:
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = (kwindows / max(launches, 1)) * FLOP_PER_WINDOW / avg_launch_s / 1e12
-        touch, cov, mod = summ.fetch()
+        if communicator is None:
+            check = [int(a.sum()) for a in summ.fetch()]
+        else:                                 # the slices of all ranks together are the merged counters
+            check = [sum(r["slice_sums"][k] for r in per_rank) for k in range(3)]
         traffic = measured_traffic(args.precision)
         out = {
             "metric": "base-positions/sec (whole node), E. coli 5mC wd21/f7 BiLSTM",
@@ -372,13 +378,15 @@ def main():
                          "peak_note": P["peak_note"],
                          "matrix_pipe_busy_est": achieved * P.get("issued_per_algorithmic", 1.0) / P["peak"],
                          "issued_tflops": achieved * P.get("issued_per_algorithmic", 1.0), "power": power_evidence(args.precision)},
-            "summary_check": {"touch": int(touch.sum()), "cov": int(cov.sum()), "mod": int(mod.sum()),
-                              "note": "rank 0's counters after the reduce = sum over all ranks"},
+            "summary_check": {"touch": check[0], "cov": check[1], "mod": check[2],
+                              "note": "counter totals after the merge (N > 1: the ranks' slices of the reduce-scatter added up)"},
         }
         if communicator is not None:
-            out["multi_gpu"] = dict(communicator.stats(), collective="ncclReduce(int32 sum, root 0) via dm_summary_reduce on one persistent "
-                                    "dm_comm", reduce_bytes_per_rank=12 * CONTIG_LEN, per_rank=per_rank,
-                                    note="`collectives` / `bytes` count one untimed warm-up reduce of the same size and the timed one")
+            out["multi_gpu"] = dict(communicator.stats(), collective="ncclReduceScatter(int32 sum) x 3 counter arrays via dm_summary_reduce_scatter "
+                                    "on one persistent dm_comm: rank r is left with the merged counters of positions [r, r + 1) * ceil(L / N)",
+                                    reduce_bytes_per_rank=12 * CONTIG_LEN, per_rank=per_rank,
+                                    measured_on_hardware_with_more_than_one_rank=bool(world > 1),
+                                    note="`collectives` / `bytes` count one untimed warm-up merge of the same size and the timed one")
         if world == 1 and not args.no_extras:
             out["extras"] = extras(m, _lib, model, args.precision, x_dev[0], x0, prob_dev, cls_dev)
         if world == 1 and not args.no_cpu_baseline:

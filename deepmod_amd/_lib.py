@@ -69,10 +69,13 @@ SIGNATURES = [
     ("dm_comm_max_f64", _c.c_int, [_vp, _c.POINTER(_c.c_double)]),
     ("dm_comm_stats", _c.c_int, [_vp, _c.POINTER(_i64), _c.POINTER(_i64)]),
     ("dm_summary_reduce", _c.c_int, [_vp, _vp, _c.c_int]),
+    ("dm_summary_reduce_scatter", _c.c_int, [_vp, _vp, _c.POINTER(_i64), _c.POINTER(_i64)]),
+    ("dm_summary_fetch_slice", _c.c_int, [_vp, _vp, _vp, _vp]),
     ("dm_summary_fetch", _c.c_int, [_vp, _vp, _vp, _vp]),
     ("dm_summary_device_ptr", _vp, [_vp]),
     ("dm_summary_follow", _c.c_int, [_vp, _vp]),
     ("dm_bed_format", _i64, [_c.c_char_p, _c.c_char, _c.c_char, _vp, _vp, _vp, _i64, _vp, _i64]),
+    ("dm_bed_format_at", _i64, [_c.c_char_p, _c.c_char, _c.c_char, _i64, _vp, _vp, _vp, _i64, _vp, _i64]),
     ("dm_cluster_create", _vp, [_c.c_int, _vp, _c.c_size_t]),
     ("dm_cluster_destroy", None, [_vp]),
     ("dm_cluster_predict", _c.c_int, [_vp, _vp, _i64, _vp]),

@@ -47,10 +47,29 @@ class FileRendezvous:
             fh.write(data)
         os.replace(tmp, self._path(name))
 
+    ABORT = 'ABORT'
+
+    def abort(self, reason: str) -> None:
+        """A rank that fails says so: every other rank's next (or current) wait ends within milliseconds instead of the timeout."""
+        try:
+            self.put(self.ABORT, ('rank %d: %s' % (self.rank, reason)).encode('utf-8', 'replace'))
+        except OSError:
+            pass
+
+    def _aborted(self):
+        path = self._path(self.ABORT)
+        if os.path.exists(path) and os.path.getmtime(path) >= self.fresh_after:
+            with open(path, 'rb') as fh:
+                return fh.read().decode('utf-8', 'replace')
+        return None
+
     def get(self, name: str) -> bytes:
         deadline = time.time() + self.timeout
         path = self._path(name)
         while not (os.path.exists(path) and os.path.getmtime(path) >= self.fresh_after):
+            why = self._aborted()
+            if why is not None:
+                raise RuntimeError('rendezvous aborted by ' + why)
             if time.time() > deadline:
                 raise TimeoutError('rendezvous: %s did not appear within %.0f s' % (path, self.timeout))
             time.sleep(0.005)

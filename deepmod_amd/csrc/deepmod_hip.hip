@@ -469,8 +469,17 @@ struct dm_model {
     float f16_max_abs = 0.0f;             // largest |packed weight| (x exponent scale)
     bool f16_ok = true;                   // every packed weight is a finite f16 (checked at create; else the default is DM_PREC_F32)
     int len_shift = 0;                    // DM_INFO_F16_LENGTH_SHIFT
-    int* range_flag = nullptr;            // host-mapped word the f16x3 kernel sets on an input it cannot represent
+    // DM_ERANGE bookkeeping: host-mapped words the split-f16 kernels set on an input they cannot represent.  A launch writes
+    // the CURRENT slot; dm_model_mark(i) ties the current slot to marker i and moves on to a free one, so that
+    // dm_model_wait_mark(i) reports exactly the launches queued between the marker before it and marker i, and a later
+    // batch that is still in flight cannot leak into (or be cleared by) the check of an earlier one.
+    static constexpr int RANGE_SLOTS = 2 * DM_MARKS + 2;
+    int* range_flag = nullptr;            // [RANGE_SLOTS]
     int* d_range_flag = nullptr;          // its device address
+    int range_cur = 0;                    // slot of the launches being queued now
+    int mark_slot[DM_MARKS];              // slot tied to marker i, -1: none
+    std::vector<int> range_orphans;       // slots of markers that were re-recorded before anybody waited for them: checked by dm_model_sync
+    bool slot_free[RANGE_SLOTS];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     hipEvent_t marks[DM_MARKS] = {};     // dm_model_mark / dm_model_wait_mark
     size_t events_used = 0;
@@ -481,7 +490,10 @@ struct dm_model {
 struct dm_summary {
     int device = 0;
     int64_t length = 0;
-    int* d_counts = nullptr;  // touch | cov | mod
+    int* d_counts = nullptr;  // touch | cov | mod  (+ SLACK ints: a reduce-scatter reads up to nranks - 1 positions past the last array)
+    static constexpr int64_t SLACK = 64;
+    int* d_slice = nullptr;   // dm_summary_reduce_scatter: this rank's slice of the three arrays, [3][slice_chunk]
+    int64_t slice_chunk = 0, slice_first = 0, slice_count = -1;   // slice_count < 0: no scatter result held
     int* d_oob = nullptr;
     long long* d_pos = nullptr;
     unsigned char* d_flags = nullptr;
@@ -624,7 +636,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         if (rcp) return rcp;
         p.plogit = m->d_plogit;
         p.len_scale = std::ldexp(1.0f, -m->len_shift);
-        p.range_flag = m->d_range_flag;
+        p.range_flag = m->d_range_flag + m->range_cur;
         const int grid = std::min(2 * p.ntiles, m->grid_cap);
         if (i8) hipLaunchKernelGGL(bilstm_f16s_kernel<1>, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
         else hipLaunchKernelGGL(bilstm_f16s_kernel<0>, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
@@ -658,7 +670,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         }
         p.plogit = m->d_plogit;
         p.len_scale = std::ldexp(1.0f, -m->len_shift);
-        p.range_flag = m->d_range_flag;
+        p.range_flag = m->d_range_flag + m->range_cur;
         const int grid = std::min(p.dir_split ? 2 * p.ntiles : p.ntiles, m->grid_cap);
         hipLaunchKernelGGL(bilstm_f16x3_kernel, dim3(grid), dim3(THREADS), LDS_BYTES + DM16_TRACE2_LDS, m->stream, p);
         if (p.dir_split) {
@@ -707,19 +719,38 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
     return DM_OK;
 }
 
-// after the model's stream has been synchronised: did an f16x3 launch meet an input it cannot represent?
-int check_range(dm_model* m) {
-    if (m->range_flag && *reinterpret_cast<volatile int*>(m->range_flag)) {
-        *reinterpret_cast<volatile int*>(m->range_flag) = 0;
-        return fail(DM_ERANGE, "DM_PREC_F16X3: an input feature is outside the representable range (features 0-5: |x| <= 65504, "
-                    "feature 6: |x| <= 65504 * 2^%d, no NaN); the results of this call are invalid - repeat it with DM_PREC_F32",
-                    m->len_shift);
+int range_error(dm_model* m) {
+    return fail(DM_ERANGE, "DM_PREC_F16X3: an input feature is outside the representable range (features 0-5: |x| <= 65504, "
+                "feature 6: |x| <= 65504 * 2^%d, no NaN); the results of these launches are invalid - repeat them with DM_PREC_F32",
+                m->len_shift);
+}
+// the launches that wrote `slot` have finished: did one of them meet an input it cannot represent?  The slot is cleared.
+bool take_range_slot(dm_model* m, int slot) {
+    volatile int* f = reinterpret_cast<volatile int*>(m->range_flag) + slot;
+    const bool bad = *f != 0;
+    *f = 0;
+    return bad;
+}
+// after the model's stream has been synchronised: every slot is final - the current one, the markers', the orphans'
+int check_range_all(dm_model* m) {
+    if (!m->range_flag) return DM_OK;
+    bool bad = take_range_slot(m, m->range_cur);
+    for (int i = 0; i < DM_MARKS; ++i)
+        if (m->mark_slot[i] >= 0) {
+            bad |= take_range_slot(m, m->mark_slot[i]);
+            m->slot_free[m->mark_slot[i]] = true;
+            m->mark_slot[i] = -1;
+        }
+    for (int sl : m->range_orphans) {
+        bad |= take_range_slot(m, sl);
+        m->slot_free[sl] = true;
     }
-    return DM_OK;
+    m->range_orphans.clear();
+    return bad ? range_error(m) : DM_OK;
 }
 int sync_and_check(dm_model* m) {
     HIP_TRY(hipStreamSynchronize(m->stream));
-    return check_range(m);
+    return check_range_all(m);
 }
 
 int predict_common(dm_model* m, const float* x, long long xstride, int64_t x_floats_total, int64_t n,
@@ -832,8 +863,13 @@ int model_init(dm_model* m, const float* weights) {
 #endif
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_f32_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_BYTES)));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->range_flag), sizeof(int), hipHostMallocMapped));
-    *m->range_flag = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->range_flag), sizeof(int) * dm_model::RANGE_SLOTS, hipHostMallocMapped));
+    for (int i = 0; i < dm_model::RANGE_SLOTS; ++i) {
+        m->range_flag[i] = 0;
+        m->slot_free[i] = i != 0;
+    }
+    for (int i = 0; i < DM_MARKS; ++i) m->mark_slot[i] = -1;
+    m->range_cur = 0;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_range_flag), m->range_flag, 0));
     {   // trained kernels far outside the usual range cannot be split into f16 halves: such a model runs the fp32 kernel
         Packed16 P16 = pack_weights_tile(weights);
@@ -1087,6 +1123,23 @@ int dm_model_mark(dm_model* m, int i) {
     HIP_TRY(hipSetDevice(m->device));
     if (!m->marks[i]) HIP_TRY(hipEventCreateWithFlags(&m->marks[i], hipEventDisableTiming));
     HIP_TRY(hipEventRecord(m->marks[i], m->stream));
+    // the launches queued since the marker before this one wrote range slot range_cur: it now belongs to marker i
+    if (m->mark_slot[i] >= 0) m->range_orphans.push_back(m->mark_slot[i]);      // re-recorded unwaited: dm_model_sync reports it
+    int next = -1;
+    for (int k = 0; k < dm_model::RANGE_SLOTS; ++k)
+        if (m->slot_free[k]) {
+            next = k;
+            break;
+        }
+    if (next < 0) {
+        // every slot is tied to a marker nobody waited for: keep writing the same slot (its launches are then reported with
+        // marker i as well as with the later one - conservative, never silent)
+        m->mark_slot[i] = -1;
+        return DM_OK;
+    }
+    m->mark_slot[i] = m->range_cur;
+    m->slot_free[next] = false;
+    m->range_cur = next;
     return DM_OK;
 }
 
@@ -1096,7 +1149,12 @@ int dm_model_wait_mark(dm_model* m, int i) {
     if (!m->marks[i]) return DM_OK;
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipEventSynchronize(m->marks[i]));
-    return check_range(m);
+    if (m->mark_slot[i] < 0) return DM_OK;          // reported already (or shared with a later marker, see dm_model_mark)
+    const int sl = m->mark_slot[i];
+    m->mark_slot[i] = -1;
+    const bool bad = take_range_slot(m, sl);
+    m->slot_free[sl] = true;
+    return bad ? range_error(m) : DM_OK;
 }
 
 int dm_memcpy_d2h(int device, void* dst, const void* src, size_t bytes) {
@@ -1120,11 +1178,11 @@ dm_summary* dm_summary_create(int device, int64_t length) {
     s->length = length;
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc(&s->d_counts, sizeof(int) * 3 * length) == hipSuccess &&
+              hipMalloc(&s->d_counts, sizeof(int) * (3 * length + dm_summary::SLACK)) == hipSuccess &&
               hipMalloc(&s->d_oob, sizeof(int)) == hipSuccess &&
               // on the summary's own (non-blocking) stream and waited for: a memset on the null stream is not ordered with the
               // kernels that the summary's or a followed model's stream run next (3 GB of counters take a millisecond to clear)
-              hipMemsetAsync(s->d_counts, 0, sizeof(int) * 3 * length, s->stream) == hipSuccess &&
+              hipMemsetAsync(s->d_counts, 0, sizeof(int) * (3 * length + dm_summary::SLACK), s->stream) == hipSuccess &&
               hipMemsetAsync(s->d_oob, 0, sizeof(int), s->stream) == hipSuccess &&
               hipStreamSynchronize(s->stream) == hipSuccess;
     if (!ok) {
@@ -1140,6 +1198,7 @@ void dm_summary_destroy(dm_summary* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_counts);
+    (void)hipFree(s->d_slice);
     (void)hipFree(s->d_oob);
     (void)hipFree(s->d_pos);
     (void)hipFree(s->d_flags);
@@ -1341,6 +1400,7 @@ typedef int (*fn_getid)(NcclId*);
 typedef int (*fn_init)(void**, int, NcclId, int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
+typedef int (*fn_reducescatter)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
 struct Rccl {
@@ -1349,6 +1409,7 @@ struct Rccl {
     fn_init init = nullptr;
     fn_allreduce allreduce = nullptr;
     fn_reduce reduce = nullptr;
+    fn_reducescatter reducescatter = nullptr;
     fn_destroy destroy = nullptr;
     fn_errstr errstr = nullptr;
 };
@@ -1368,6 +1429,7 @@ int load_rccl() {
     g_rccl.init = (fn_init)dlsym(h, "ncclCommInitRank");
     g_rccl.allreduce = (fn_allreduce)dlsym(h, "ncclAllReduce");
     g_rccl.reduce = (fn_reduce)dlsym(h, "ncclReduce");
+    g_rccl.reducescatter = (fn_reducescatter)dlsym(h, "ncclReduceScatter");
     g_rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
     g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
     if (!g_rccl.getid || !g_rccl.init || !g_rccl.allreduce || !g_rccl.reduce || !g_rccl.destroy)
@@ -1496,17 +1558,72 @@ int dm_summary_grow(dm_summary* s, int64_t new_length) {
     if (s->follow) HIP_TRY(hipStreamSynchronize(s->follow->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     int* nd = nullptr;
-    if (hipMalloc(&nd, sizeof(int) * 3 * new_length) != hipSuccess) {
+    if (hipMalloc(&nd, sizeof(int) * (3 * new_length + dm_summary::SLACK)) != hipSuccess) {
         (void)hipGetLastError();
         return fail(DM_ENOMEM, "cannot grow the summary to %lld positions", (long long)new_length);
     }
-    HIP_TRY(hipMemsetAsync(nd, 0, sizeof(int) * 3 * new_length, s->stream));
-    for (int k = 0; k < 3; ++k)
-        HIP_TRY(hipMemcpyAsync(nd + k * new_length, s->d_counts + k * s->length, sizeof(int) * s->length, hipMemcpyDeviceToDevice, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    hipError_t e = hipMemsetAsync(nd, 0, sizeof(int) * (3 * new_length + dm_summary::SLACK), s->stream);
+    for (int k = 0; k < 3 && e == hipSuccess; ++k)
+        e = hipMemcpyAsync(nd + k * new_length, s->d_counts + k * s->length, sizeof(int) * s->length, hipMemcpyDeviceToDevice, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(nd);                         // the old counters stay valid
+        return fail(DM_EDEVICE, "growing the summary to %lld positions failed: %s", (long long)new_length, hipGetErrorString(e));
+    }
     HIP_TRY(hipFree(s->d_counts));
     s->d_counts = nd;
     s->length = new_length;
+    s->slice_count = -1;
+    return DM_OK;
+}
+
+// Scatter form of the merge: positions are cut into nranks slices of chunk = ceil(length / nranks); after the call
+// rank r holds the sums over all ranks of touch | cov | mod for its slice [r * chunk, min(length, (r + 1) * chunk)) and formats
+// that part of the BED itself - no rank fetches or formats a whole contig.  One ncclReduceScatter per counter array (int32 sum).
+int dm_summary_reduce_scatter(dm_summary* s, dm_comm* c, int64_t* first, int64_t* count) {
+    if (!s || !c) return fail(DM_EINVAL, "null summary / communicator");
+    if (s->device != c->device) return fail(DM_EINVAL, "summary on device %d, communicator on device %d", s->device, c->device);
+    if (c->nranks > dm_summary::SLACK) return fail(DM_EINVAL, "reduce-scatter over %d ranks (at most %lld)", c->nranks, (long long)dm_summary::SLACK);
+    if (!g_rccl.reducescatter) return fail(DM_ERCCL, "librccl has no ncclReduceScatter");
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->follow) HIP_TRY(hipStreamSynchronize(s->follow->stream));   // adds queued on the classifier's stream
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const int64_t chunk = (s->length + c->nranks - 1) / c->nranks;
+    if (chunk > s->slice_chunk) {
+        (void)hipFree(s->d_slice);
+        s->d_slice = nullptr;
+        s->slice_chunk = 0;
+        HIP_TRY(hipMalloc(&s->d_slice, sizeof(int) * 3 * chunk));
+        s->slice_chunk = chunk;
+    }
+    for (int k = 0; k < 3; ++k) {
+        // the send buffer of array k is read up to nranks * chunk <= length + nranks - 1 positions: past `length` that is the head of
+        // the next array (or the allocation's slack) - sums of positions that do not exist, never looked at
+        int e = g_rccl.reducescatter(s->d_counts + k * s->length, s->d_slice + k * s->slice_chunk, size_t(chunk), NCCL_INT32, NCCL_SUM, c->comm, c->stream);
+        if (e) return fail(DM_ERCCL, "ncclReduceScatter: %s", rccl_err(e));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ++c->reduces;
+    c->reduced_bytes += int64_t(3) * s->length * 4;
+    s->slice_first = std::min<int64_t>(s->length, int64_t(c->rank) * chunk);
+    s->slice_count = std::min<int64_t>(s->length, int64_t(c->rank + 1) * chunk) - s->slice_first;
+    if (first) *first = s->slice_first;
+    if (count) *count = s->slice_count;
+    return DM_OK;
+}
+
+// this rank's slice after dm_summary_reduce_scatter: `count` int32 each (any may be NULL)
+int dm_summary_fetch_slice(dm_summary* s, int32_t* touch, int32_t* cov, int32_t* mod) {
+    if (!s) return fail(DM_EINVAL, "null summary");
+    if (s->slice_count < 0) return fail(DM_ESTATE, "no reduce-scatter result: call dm_summary_reduce_scatter first");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc0 = summary_check_oob(s);
+    if (rc0) return rc0;
+    const size_t bytes = sizeof(int) * size_t(s->slice_count);
+    if (bytes == 0) return DM_OK;
+    if (touch) HIP_TRY(hipMemcpy(touch, s->d_slice, bytes, hipMemcpyDeviceToHost));
+    if (cov) HIP_TRY(hipMemcpy(cov, s->d_slice + s->slice_chunk, bytes, hipMemcpyDeviceToHost));
+    if (mod) HIP_TRY(hipMemcpy(mod, s->d_slice + 2 * s->slice_chunk, bytes, hipMemcpyDeviceToHost));
     return DM_OK;
 }
 

@@ -473,6 +473,13 @@ def _run_processes(ctx, target, argsets, what, poll=None):
     for p in procs:
         p.start()
     while any(p.is_alive() for p in procs):
+        # a worker that died takes the run down at once: the ranks of a streaming run sit in collectives (communicator
+        # creation, the final reduce) that a dead rank never joins - waiting for the others to end would wait for ever
+        if any(p.exitcode not in (None, 0) for p in procs):
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            break
         if poll is None or not poll():
             time.sleep(0.02)
     for p in procs:
@@ -609,6 +616,10 @@ def mDetect_manager(moptions):
     """The detect run (counterpart of myDetect.py:1124-1263): inputs -> worker batches -> detect -> per-position summary
     -> `<outFolder>.done`.  predDet == 1 runs the streaming mode unless `storePred` asks for the reference's per-read
     files; predDet == 0 summarises the stored predictions under `predpath` (bin/DeepMod.py:143-148)."""
+    if moptions.get('mod_cluster'):
+        # the reference marks this branch of sum_handler "should not used now" (myDetect.py:1054-1087); neither run mode builds it,
+        # and writing plain mod_pos.* files for a run that asked for cluster_mod_pos.* would be a silent change of meaning
+        raise NotImplementedError("--mod_cluster 1 is not built (the reference marks that branch 'should not used now', myDetect.py:1054)")
     ctx = multiprocessing.get_context('spawn')      # never fork a process that may hold a HIP context
     pmanager = ctx.Manager()
     ngpu = max(1, int(moptions.get('gpus', 1)))

@@ -57,7 +57,12 @@ def load(path: str) -> Dict[str, np.ndarray]:
             fallback.append(name)
             continue
         count = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
-        arr = np.frombuffer(mm, dtype, count, cur.pos)
+        if cur.pos % max(dtype.alignment, 1):
+            # a member starts wherever the zip local header ends: a view at an offset that is not a multiple of the item alignment
+            # would hand misaligned int64 / float64 pointers to the C ABI - such a member is copied
+            arr = np.frombuffer(mm, np.uint8, count * dtype.itemsize, cur.pos).copy().view(dtype)
+        else:
+            arr = np.frombuffer(mm, dtype, count, cur.pos)
         out[name] = arr.reshape(shape, order='F' if fortran else 'C')
     if fallback:
         z = np.load(path, allow_pickle=False)

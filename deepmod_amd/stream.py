@@ -834,17 +834,23 @@ class StreamEngine:
         for k, v in getattr(self.backend, 'timing', {}).items():
             self.stats['submit_' + k] += v
 
-    def finalize(self, gather, reduce_fn, write: bool = True) -> Dict[Tuple[str, str], bytes]:
-        """Merge over ranks and write the BED files on rank 0.
-        gather(obj) -> list of every rank's obj (control plane); reduce_fn(summary) sums one summary over the ranks
-        into rank 0 (data plane).  All ranks walk the union of contig x strand keys in the same order."""
+    def finalize(self, gather, scatter_fn=None, write: bool = True, reduce_fn=None) -> Dict[Tuple[str, str], bytes]:
+        """Merge over ranks and write the BED files.
+        gather(obj) -> list of every rank's obj (control plane).  Data plane, world > 1:
+          * scatter_fn(summary) -> (first, count): the summary's counters are summed over the ranks and THIS rank is left with the
+            slice [first, first + count) (dm_summary_reduce_scatter).  Every rank fetches and formats its slice and writes it as a
+            part file; rank 0 concatenates the parts in rank order (BED lines are sorted by position, so that IS the file).  No rank
+            ever holds, downloads or formats a whole contig - for a human genome that is 74 GB of counters and 6e8 lines.
+          * reduce_fn(summary) (fallback when no scatter_fn is given): sum into rank 0, which fetches and formats everything.
+        All ranks walk the union of contig x strand keys in the same order.  Returns the BED bytes rank 0 assembled."""
         from . import summary as dmsum
         t0 = time.perf_counter()
         mine = {"%s\t%s" % k: self.summaries[k].length for k in self.summaries}
         lens = dict(self.ref_len)
         everyone = gather({"keys": mine, "len": lens}) if self.world > 1 else [{"keys": mine, "len": lens}]
         keys = sorted(set(k for e in everyone for k in e["keys"]))
-        beds = {}
+        beds, parts = {}, {}
+        out_path = lambda chrom, strand: '%s/mod_pos.%s%s.%s.bed' % (self.mo['outFolder'], chrom, strand, self.mo['Base'])
         for key in keys:
             chrom, strand = key.split("\t")
             length = max([e["keys"].get(key, 0) for e in everyone] + [e["len"].get(chrom, 0) for e in everyone])
@@ -852,17 +858,51 @@ class StreamEngine:
             if s is None:                               # this rank saw no read of that contig x strand: zeros
                 s = self.summaries[(chrom, strand)] = self.backend.new_summary(length)
             s.grow(length)                              # exactly the common length (no growth slack): equal counts on every rank
-            if self.world > 1:
-                reduce_fn(s)
-            if self.rank == 0:
-                touch, cov, mod = s.fetch()
-                bed = dmsum.bed_lines(chrom, strand, self.mo['Base'], touch, cov, mod)
-                beds[(chrom, strand)] = bed
-                if write and len(bed) > 0:          # the reference writes no file for an empty table (myDetect.py:1109)
-                    with open('%s/mod_pos.%s%s.%s.bed' % (self.mo['outFolder'], chrom, strand, self.mo['Base']), 'wb') as fh:
-                        fh.write(bed)
+            if self.world > 1 and scatter_fn is not None:
+                s.sync()                                # every rank: positions this rank dropped as out of range fail the run here
+                first, count = scatter_fn(s)
+                touch, cov, mod = s.fetch_slice()
+                part = dmsum.bed_lines(chrom, strand, self.mo['Base'], touch, cov, mod, first_pos=first)
+                parts[key] = len(part)
+                if write:
+                    with open(out_path(chrom, strand) + '.part%d' % self.rank, 'wb') as fh:
+                        fh.write(part)
+                else:
+                    beds[(chrom, strand)] = part        # (tests: the caller joins the ranks' parts itself)
+                self.stats['bed_bytes'] += len(part)
+            else:
+                if self.world > 1:
+                    s.sync()
+                    reduce_fn(s)
+                if self.rank == 0:
+                    touch, cov, mod = s.fetch()
+                    bed = dmsum.bed_lines(chrom, strand, self.mo['Base'], touch, cov, mod)
+                    beds[(chrom, strand)] = bed
+                    if write and len(bed) > 0:          # the reference writes no file for an empty table (myDetect.py:1109)
+                        with open(out_path(chrom, strand), 'wb') as fh:
+                            fh.write(bed)
             s.close()
         self.summaries = {}
+        if self.world > 1 and scatter_fn is not None and write:
+            # every rank's parts are on disk once its sizes have been gathered; rank 0 joins them
+            sizes = gather({"parts": parts})
+            if self.rank == 0:
+                for key in keys:
+                    chrom, strand = key.split("\t")
+                    names = [out_path(chrom, strand) + '.part%d' % r for r in range(self.world)]
+                    total = sum(e["parts"].get(key, 0) for e in sizes)
+                    if total > 0:                       # the reference writes no file for an empty table (myDetect.py:1109)
+                        with open(out_path(chrom, strand), 'wb') as out:
+                            for r, nm in enumerate(names):
+                                with open(nm, 'rb') as fh:
+                                    data = fh.read()
+                                if len(data) != sizes[r]["parts"].get(key, 0):
+                                    raise RuntimeError('BED part %s has %d bytes, its rank reported %d' % (nm, len(data), sizes[r]["parts"].get(key, 0)))
+                                out.write(data)
+                            beds[(chrom, strand)] = None
+                    for nm in names:
+                        if os.path.exists(nm):
+                            os.remove(nm)
         self.stats['merge+bed'] += time.perf_counter() - t0
         return beds
 
@@ -887,6 +927,18 @@ def stream_rank_main(moptions, rank: int, world: int, device: int, work, result_
     communicator = rdv = None
     if world > 1:       # collectively, before any work: a rank that cannot join fails the run at once, not after its share of the reads
         rdv = dmcomm.FileRendezvous(os.path.join(moptions['outFolder'], '.rendezvous'), rank, world)
+    try:
+        return _stream_rank_body(moptions, rank, world, device, work, result_q, feeders, feeder_procs, rdv)
+    except BaseException as exc:
+        if rdv is not None:
+            rdv.abort('%s: %s' % (type(exc).__name__, exc))      # the other ranks stop waiting for this one within milliseconds
+        raise
+
+
+def _stream_rank_body(moptions, rank, world, device, work, result_q, feeders, feeder_procs, rdv):
+    from . import comm as dmcomm, signal as dmsignal
+    communicator = None
+    if world > 1:
         communicator = dmcomm.Communicator.from_rendezvous(device, rdv)
     use_procs = feeder_procs > 0 and hasattr(work, 'get')
     backend = None if use_procs else HipBackend(moptions, device)       # with feeder processes: created once they are running
@@ -901,11 +953,12 @@ def stream_rank_main(moptions, rank: int, world: int, device: int, work, result_
         batches = _drain(work) if hasattr(work, 'get') else iter(work)
         eng.run(batches, feeders=feeders, make_normalizer=lambda: dmsignal.SignalNormalizer(device))
     if communicator is not None:
-        gather = lambda obj: rdv.all_gather_json('summary_keys', obj)
-        reduce_fn = lambda s: s.reduce(communicator, 0)
+        rounds = iter(range(1 << 30))
+        gather = lambda obj: rdv.all_gather_json('finalize_%d' % next(rounds), obj)
+        scatter_fn = lambda s: s.reduce_scatter(communicator)
     else:
-        gather = reduce_fn = None
-    eng.finalize(gather, reduce_fn)
+        gather = scatter_fn = None
+    eng.finalize(gather, scatter_fn)
     if communicator is not None:
         eng.stats.update({'comm_' + k: v for k, v in communicator.stats().items()})
         communicator.close()

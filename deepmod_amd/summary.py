@@ -91,22 +91,39 @@ class PositionSummary:
         reduce to `root` (result valid there), or an all-reduce with root < 0.  Collective: every rank calls it."""
         _lib.check(self._lib.dm_summary_reduce(self._h, comm._h, root))
 
+    def reduce_scatter(self, comm) -> Tuple[int, int]:
+        """The merge that scales: afterwards this rank owns the all-rank sums of positions [first, first + count) - one
+        ncclReduceScatter per counter array (dm_summary_reduce_scatter).  Collective.  -> (first, count)"""
+        import ctypes
+        first, count = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self._lib.dm_summary_reduce_scatter(self._h, comm._h, ctypes.byref(first), ctypes.byref(count)))
+        self._slice = (first.value, count.value)
+        return self._slice
 
-def bed_lines(chrom: str, strand: str, base: str, touch: np.ndarray, cov: np.ndarray, mod: np.ndarray) -> bytes:
+    def fetch_slice(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(touch, cov, mod) of this rank's slice after reduce_scatter."""
+        n = self._slice[1]
+        out = [np.empty(n, np.int32) for _ in range(3)]
+        _lib.check(self._lib.dm_summary_fetch_slice(self._h, *[a.ctypes.data for a in out]))
+        return tuple(out)
+
+
+def bed_lines(chrom: str, strand: str, base: str, touch: np.ndarray, cov: np.ndarray, mod: np.ndarray, first_pos: int = 0) -> bytes:
     """BED text exactly as the reference writes it (myDetect.py:1112-1120): one line per position
     whose key was created (touch > 0), sorted by position, single spaces, trailing space before the
-    newline, column 5 = min(cov, 1000), pct = trunc(100*mod/max(cov,1)).  Formatted by dm_bed_format (host C)."""
+    newline, column 5 = min(cov, 1000), pct = trunc(100*mod/max(cov,1)).  Formatted by dm_bed_format_at (host C);
+    first_pos: the position of element 0 (a rank's slice of the contig after reduce_scatter)."""
     lib = _lib.load()
     touch = np.ascontiguousarray(touch, np.int32)
     cov = np.ascontiguousarray(cov, np.int32)
     mod = np.ascontiguousarray(mod, np.int32)
     n = len(touch)
-    args = (chrom.encode("ascii"), strand.encode("ascii"), base.encode("ascii"), touch.ctypes.data, cov.ctypes.data, mod.ctypes.data, n)
-    bound = lib.dm_bed_format(*args, None, 0)
+    args = (chrom.encode("ascii"), strand.encode("ascii"), base.encode("ascii"), int(first_pos), touch.ctypes.data, cov.ctypes.data, mod.ctypes.data, n)
+    bound = lib.dm_bed_format_at(*args, None, 0)
     if bound < 0:
         raise _lib.DeepModHipError("dm_bed_format: " + _lib.last_error())
     buf = np.empty(max(int(bound), 1), np.uint8)
-    got = lib.dm_bed_format(*args, buf.ctypes.data, int(bound))
+    got = lib.dm_bed_format_at(*args, buf.ctypes.data, int(bound))
     if got < 0 or got > bound:
         raise _lib.DeepModHipError("dm_bed_format: " + _lib.last_error())
     return buf[:got].tobytes()

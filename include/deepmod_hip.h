@@ -147,7 +147,8 @@ int dm_model_h2d_async(dm_model* m, void* dst, const void* src, size_t bytes);
 /* Page-locked host staging memory (hipHostMalloc) and stream markers for a pipelined worker: batch k is copied into staging
  * set k % N while the device still works on batch k - 1; dm_model_mark(m, i) records a marker on the model's stream after the
  * launches that read set i, dm_model_wait_mark(m, i) blocks the host until that marker has passed (at once if it was never
- * recorded; a DM_ERANGE of the launches before the marker is reported here, as by dm_model_sync).  i in [0, DM_MARKS).  No reference counterpart: the reference feeds numpy arrays to session.run
+ * recorded).  DM_ERANGE is tracked per marker: wait_mark(i) reports exactly the launches queued between the marker recorded before i and
+ * marker i - a later batch still in flight is neither reported early nor cleared; dm_model_sync reports everything outstanding.  i in [0, DM_MARKS).  No reference counterpart: the reference feeds numpy arrays to session.run
  * (myDetect.py:796-822). */
 #define DM_MARKS 8
 void* dm_host_alloc(int device, size_t bytes);
@@ -199,6 +200,14 @@ int dm_comm_barrier(dm_comm* c);
 int dm_comm_max_f64(dm_comm* c, double* value);
 int dm_comm_stats(const dm_comm* c, int64_t* collectives, int64_t* bytes);
 int dm_summary_reduce(dm_summary* s, dm_comm* c, int root);
+/*   dm_summary_reduce_scatter   the merge that scales (the reference's per-process BED files + sum_chr_mod.py:47-63 turned
+ *                       inside out): positions are cut into nranks slices of ceil(length / nranks); afterwards THIS rank holds the
+ *                       all-rank sums of its slice [*first, *first + *count) (count 0 for a rank past the end) - one ncclReduceScatter
+ *                       (int32 sum) per counter array.  Each rank then fetches and formats only its slice (dm_summary_fetch_slice,
+ *                       dm_bed_format_at) and the parts are concatenated in rank order.  Collective, nranks <= 64.
+ *   dm_summary_fetch_slice      that slice: *count int32 each (any may be NULL) */
+int dm_summary_reduce_scatter(dm_summary* s, dm_comm* c, int64_t* first, int64_t* count);
+int dm_summary_fetch_slice(dm_summary* s, int32_t* touch, int32_t* cov, int32_t* mod);
 
 /* copy counters to host arrays of `length` int32 each (any may be NULL) */
 int dm_summary_fetch(dm_summary* s, int32_t* touch, int32_t* cov, int32_t* mod);
@@ -216,6 +225,10 @@ int dm_summary_follow(dm_summary* s, dm_model* m);
  * that bound is returned: allocate it and call again. */
 int64_t dm_bed_format(const char* chrom, char strand, char base, const int32_t* touch, const int32_t* cov, const int32_t* mod,
                       int64_t length, char* out, int64_t cap);
+/* the same for counters of positions [first_pos, first_pos + length): a rank's slice of the text (myDetect.py:1112-1120 is sorted by
+ * position, so the ranks' parts concatenated in rank order are the file) */
+int64_t dm_bed_format_at(const char* chrom, char strand, char base, int64_t first_pos, const int32_t* touch, const int32_t* cov,
+                         const int32_t* mod, int64_t length, char* out, int64_t cap);
 
 /* ------------------------------------------------------------- CpG cluster second stage -- */
 /*

@@ -27,6 +27,21 @@ class CpuSummary:
         L = self.length
         return self.counts[:L].copy(), self.counts[L:2 * L].copy(), self.counts[2 * L:].copy()
 
+    def sync(self):
+        pass
+
+    def take_slice(self, rank, world):
+        """dm_summary_reduce_scatter's slice rule (the counters must already hold the all-rank sums: the transport stand-in of
+        the test all-reduces them): chunk = ceil(length / world), this rank owns [rank * chunk, min(length, (rank + 1) * chunk))."""
+        chunk = -(-self.length // world)
+        first = min(self.length, rank * chunk)
+        self._slice = (first, min(self.length, (rank + 1) * chunk) - first)
+        return self._slice
+
+    def fetch_slice(self):
+        L, (first, count) = self.length, self._slice
+        return tuple(self.counts[k * L + first:k * L + first + count].copy() for k in range(3))
+
     def close(self):
         pass
 

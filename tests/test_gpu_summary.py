@@ -89,6 +89,30 @@ def test_persistent_communicator_single_rank(gpu_device, tmp_path):
     c.close()
 
 
+def test_reduce_scatter_single_rank_and_sliced_bed(gpu_device, tmp_path):
+    """dm_summary_reduce_scatter with nranks = 1 (ncclReduceScatter really runs; the slice is the whole contig) and the slice
+    formatter: the text of [first, first + count) pieces concatenated equals the text of the whole contig."""
+    from deepmod_amd import comm
+    rdv = comm.FileRendezvous(str(tmp_path / 'rdv'), 0, 1)
+    c = comm.Communicator.from_rendezvous(gpu_device, rdv)
+    for i, length in enumerate((1001, 70003)):
+        s = summary.PositionSummary(length, gpu_device)
+        pos, flags = _random_bases(9000, length, seed=10 + i)
+        s.add(pos, flags)
+        whole = s.fetch()
+        assert s.reduce_scatter(c) == (0, length)
+        for a, b in zip(s.fetch_slice(), whole):
+            assert np.array_equal(a, b)
+        bed = summary.bed_lines('chrQ', '-', 'C', *whole)
+        cuts = [0, length // 3, length // 3 + 1, length - 5, length]
+        parts = [summary.bed_lines('chrQ', '-', 'C', *[a[lo:hi] for a in whole], first_pos=lo) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        assert b''.join(parts) == bed and len(bed) > 0
+        s.close()
+    st = c.stats()
+    assert st["collectives"] == 2 and st["bytes"] == 12 * (1001 + 70003)
+    c.close()
+
+
 def test_summary_grow_keeps_counts(gpu_device):
     s = summary.PositionSummary(1000, gpu_device)
     pos, flags = _random_bases(20000, 1000, seed=4)

@@ -39,11 +39,19 @@ def gather(obj):
     dist.all_gather_object(out, obj)
     return out
 
-def reduce_fn(s):                      # transport stand-in: gloo reduce of the host counters into rank 0
+def scatter_fn(s):                     # transport stand-in for ncclReduceScatter: gloo all-reduce of the host counters, then the slice rule
+    t = torch.from_numpy(s.counts)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return s.take_slice(rank, world)
+
+def reduce_fn(s):                      # the rank-0 form of the merge (dm_summary_reduce)
     t = torch.from_numpy(s.counts)
     dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
 
-eng.finalize(gather if world > 1 else None, reduce_fn if world > 1 else None)
+if cfg.get("merge") == "reduce":
+    eng.finalize(gather if world > 1 else None, None, reduce_fn=reduce_fn if world > 1 else None)
+else:
+    eng.finalize(gather if world > 1 else None, scatter_fn if world > 1 else None)
 json.dump({"rank": rank, "reads": eng.stats["reads"], "windows": eng.stats["windows"], "errors": dict(eng.errors)},
           open(os.path.join(cfg["out"], "stats.%d.json" % rank), "w"))
 if world > 1:
@@ -92,27 +100,30 @@ def test_two_rank_streaming_engine_equals_single_process_and_oracle(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     outs = {}
-    for world in (1, 2):
-        out = tmp_path / ("out%d" % world)
-        cfg = tmp_path / ("cfg%d.json" % world)
-        cfg.write_text(json.dumps({"files": all_files, "out": str(out), "seed": 26, "scale": 4.0}))
+    # world 2 and 3 (3: slices of unequal length, 5000 and 6000 positions do not divide) through the reduce-scatter merge
+    # (every rank formats its slice of every contig, rank 0 joins the parts), world 2 also through the reduce-to-rank-0 merge
+    for tag, world, merge in (("1", 1, "scatter"), ("2", 2, "scatter"), ("3", 3, "scatter"), ("2r", 2, "reduce")):
+        out = tmp_path / ("out" + tag)
+        cfg = tmp_path / ("cfg%s.json" % tag)
+        cfg.write_text(json.dumps({"files": all_files, "out": str(out), "seed": 26, "scale": 4.0, "merge": merge}))
         env = dict(os.environ, DM_ROOT=ROOT, DM_CFG=str(cfg))
         if world == 1:
             cmd = [sys.executable, str(script)]
         else:
-            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                   "--master-port", "29517", str(script)]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+                   "--master-port", str(29517 + world), str(script)]
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-3000:]
-        outs[world] = {k: open('%s/mod_pos.%s%s.C.bed' % (out, k[0], k[1]), 'rb').read() for k in want}
+        outs[tag] = {k: open('%s/mod_pos.%s%s.C.bed' % (out, k[0], k[1]), 'rb').read() for k in want}
+        assert not [f for f in os.listdir(out) if '.part' in f]        # the parts were joined and removed
         stats = [json.load(open(out / ("stats.%d.json" % r))) for r in range(world)]
         assert sum(s["reads"] for s in stats) == 12
         assert sum(len(v) for s in stats for v in s["errors"].get("Less Event", [])) > 0
-        if world == 2:
-            assert all(s["reads"] > 0 for s in stats)          # both ranks did part of the work
+        if world > 1:
+            assert all(s["reads"] > 0 for s in stats)          # every rank did part of the work
     for k in want:
-        assert outs[1][k] == want[k]
-        assert outs[2][k] == want[k]
+        for tag in outs:
+            assert outs[tag][k] == want[k], (tag, k)
 
 
 def test_shard_partitions_everything():
@@ -122,6 +133,21 @@ def test_shard_partitions_everything():
         parts = [comm.shard(items, r, world) for r in range(world)]
         assert sorted(sum(parts, [])) == items
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_file_rendezvous_abort_ends_a_wait_at_once(tmp_path):
+    """A rank that fails writes the abort file; the ranks waiting for it raise within milliseconds instead of the timeout."""
+    import threading
+    import time
+    import pytest
+    from deepmod_amd import comm
+    a = comm.FileRendezvous(str(tmp_path), 0, 2, timeout=60)
+    b = comm.FileRendezvous(str(tmp_path), 1, 2, timeout=60)
+    threading.Timer(0.2, lambda: b.abort('RuntimeError: no such device')).start()
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match='aborted by rank 1'):
+        a.get('never_written')
+    assert time.time() - t0 < 5.0
 
 
 def test_file_rendezvous_round_trip(tmp_path):

@@ -1631,4 +1631,5 @@ int dm_summary_fetch_slice(dm_summary* s, int32_t* touch, int32_t* cov, int32_t*
 
 #include "signal.hip.inc"
 #include "readmap.inc"
+#include "rowsbatch.inc"
 #include "bedtext.inc"

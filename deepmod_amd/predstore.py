@@ -130,8 +130,9 @@ def save_packed_container(path: str, reads: List[Dict], contig_len: Dict[str, in
     arrays = {'format': np.array(2), 'tx': cat(tx, np.float32, (0, 7)), 'refbase': cat(refb, 'S1', 0), 'readbase': cat(readb, 'S1', 0),
               'refbasei': cat(refi, np.int64, 0), 'evbase': cat(evb, 'S1', 0), 'row_off': off(tx), 'bmi_off': off(refb),
               'ev_off': off(evb), 'meta': np.array(json.dumps({'reads': metas, 'contig_len': contig_len or {}}))}
+    from . import npzmap
     with open(path, 'wb') as fh:
-        np.savez(fh, **arrays)
+        npzmap.savez_aligned(fh, **arrays)          # members 64-byte aligned in the file: load_packed's views are aligned
 
 
 def load_packed(path: str) -> Dict:

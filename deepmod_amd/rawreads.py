@@ -63,8 +63,9 @@ def save_raw_container(path: str, reads: List[Dict]) -> None:
     for f in _EV_FIELDS:
         cols = [np.asarray(rd['events_data'][f], dtype=dtypes[f]) for rd in reads]
         arrays['ev_' + f] = np.concatenate(cols) if cols else np.zeros(0, dtypes[f])
+    from . import npzmap
     with open(path, 'wb') as fh:
-        np.savez(fh, **arrays)
+        npzmap.savez_aligned(fh, **arrays)          # members 64-byte aligned in the file: load_raw_container's views are aligned
 
 
 def load_raw_container(path: str) -> List[Dict]:

@@ -56,6 +56,26 @@ class SignalNormalizer:
         return mean, stdv, norm, int(first_empty.value), sig
 
 
+    def event_stats_arrays(self, raw_parts, raw_off, ev_start, ev_length, ev_off):
+        """The batched call on arrays that are already laid out back to back (stream._prepare_batch_c): raw_parts - int16 arrays
+        whose concatenation is the samples of all reads, raw_off / ev_off [n + 1] int64, ev_start / ev_length uint64 (starts relative
+        to the read's first sample).  -> (mean f32[E], stdv f32[E], first_empty int64[n])"""
+        n = len(raw_off) - 1
+        raw = raw_parts[0] if len(raw_parts) == 1 else np.concatenate(raw_parts)
+        raw = np.ascontiguousarray(raw, dtype=np.int16)
+        st = np.ascontiguousarray(ev_start, dtype=np.uint64)
+        ln = np.ascontiguousarray(ev_length, dtype=np.uint64)
+        raw_off = np.ascontiguousarray(raw_off, np.int64)
+        ev_off = np.ascontiguousarray(ev_off, np.int64)
+        mean = np.empty(len(st), np.float32)
+        stdv = np.empty(len(st), np.float32)
+        norm6 = np.empty((n, 6), np.float64)
+        first_empty = np.empty(n, np.int64)
+        _lib.check(self._lib.dm_signal_event_stats_batch(self._h, n, raw.ctypes.data, raw_off.ctypes.data, st.ctypes.data, ln.ctypes.data,
+                                                         ev_off.ctypes.data, mean.ctypes.data, stdv.ctypes.data, norm6.ctypes.data,
+                                                         first_empty.ctypes.data))
+        return mean, stdv, first_empty
+
     def event_stats_batch(self, reads):
         """reads: [(raw int16[n], ev_start uint64[E], ev_length uint64[E])] -> [(mean, stdv, norm dict, first_empty)] with one
         device round trip for the whole list (dm_signal_event_stats_batch; bit-identical to per-read event_stats)."""

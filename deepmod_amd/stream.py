@@ -21,6 +21,7 @@ gloo transport) - only the transport and the device calls are replaced, the shar
 """
 from __future__ import annotations
 
+import json
 import os
 import queue
 import threading
@@ -195,10 +196,249 @@ class _PreparedBuilder(Prepared):
         self._pieces = []
 
 
+_REF_BYTES: Dict[Optional[str], Dict[str, bytes]] = {}      # reference path -> contig -> ASCII bytes (encoded once per feeder process)
+_ROWS_ERRORS = {1: "Less Event", 2: "Prediction failed: IndexError", 4: "CIGAR-Error", 6: "No reference sequence", 7: "Error Does not match"}
+
+
+def _c_arr(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=None) -> Prepared:
+    """prepare_batch with the per-read work behind the C ABI: one dm_events_merge per raw container, one signal request, one
+    dm_rows_add_raw / dm_rows_add_packed per input kind, dm_rows_info + dm_rows_emit straight into the hand-over arrays.
+    Same Prepared (rows, pos, flags, groups, errors) as the Python path below, which stays as the restatement the tests compare
+    with (tests/test_stream_feeders.py)."""
+    import ctypes
+    from . import _lib, detect, readmap
+    lib = _lib.load()
+    out = Prepared()
+    out.files = list(files)
+    base = moptions['Base']
+    h = lib.dm_rows_create(base.encode('ascii'))
+    if not h:
+        raise _lib.DeepModHipError("dm_rows_create: " + _lib.last_error())
+    keep = []                       # arrays the handle borrows until emit
+    contigs: Dict[str, int] = {}
+    srcs: List[str] = []            # source file of every read, in the order the reads were added
+    strands_c = {'+': 0, '-': 1}
+    try:
+        t0 = time.perf_counter()
+        raw_files = [f for f in files if f.endswith(rawreads.RAW_SUFFIX)]
+        if raw_files:
+            from . import npzmap
+            normalizer = make_normalizer() if make_normalizer else None
+            if normalizer is None:
+                from . import signal as dmsignal
+                normalizer = dmsignal.SignalNormalizer(int(moptions.get('device', 0)))
+            ids, id_src, raw_parts, raw_offs, ev_offs = [], [], [], [0], [0]
+            cols = {k: [] for k in ('mean', 'stdv', 'start', 'length', 'base')}
+            for f5f in raw_files:
+                try:
+                    z = npzmap.load(f5f)
+                    if 'format' not in z:
+                        raise ValueError('format-1 raw container')
+                    meta = json.loads(str(z['meta']))
+                    n = len(meta)
+                    eo = _c_arr(z['ev_off'], np.int64)
+                    ne = int(eo[-1])
+                    ms = _c_arr(z['ev_model_state'], z['ev_model_state'].dtype)
+                    mev_off = np.empty(n + 1, np.int64)
+                    m_mean, m_stdv = np.empty(ne, np.float32), np.empty(ne, np.float32)
+                    m_start, m_len, m_base = np.empty(ne, np.uint64), np.empty(ne, np.uint64), np.empty(ne, 'S1')
+                    args = [_c_arr(z['ev_mean'], np.float64), _c_arr(z['ev_stdv'], np.float64), _c_arr(z['ev_start'], np.uint64),
+                            _c_arr(z['ev_length'], np.uint64)]
+                    mv = _c_arr(z['ev_move'], np.int64)
+                    got = lib.dm_events_merge(n, eo.ctypes.data, args[0].ctypes.data, args[1].ctypes.data, args[2].ctypes.data, args[3].ctypes.data,
+                                              ms.ctypes.data, ms.dtype.itemsize // 4, mv.ctypes.data, mev_off.ctypes.data, m_mean.ctypes.data,
+                                              m_stdv.ctypes.data, m_start.ctypes.data, m_len.ctypes.data, m_base.ctypes.data)
+                    if got < 0:
+                        raise _lib.DeepModHipError(_lib.last_error())
+                except Exception:
+                    out.errors["Cannot open fast5 or other errors"].append(f5f)
+                    print("Cannot open fast5 or other errors: {}".format(f5f))
+                    continue
+                per_read = mev_off[1:] - mev_off[:-1]
+                for i, m in enumerate(meta):
+                    rid = m['read_id'].replace(" ", ":::").replace("\t", "|||")
+                    if per_read[i] == 0:
+                        out.errors['No events data'].append(f5f)
+                        rid = None
+                    ids.append(rid)
+                    id_src.append(f5f)
+                raw_parts.append(z['raw'])
+                ro = _c_arr(z['raw_off'], np.int64)
+                raw_offs.extend((raw_offs[-1] + ro[1:]).tolist())
+                ev_offs.extend((ev_offs[-1] + mev_off[1:]).tolist())
+                cols['mean'].append(m_mean[:got]); cols['stdv'].append(m_stdv[:got]); cols['start'].append(m_start[:got])
+                cols['length'].append(m_len[:got]); cols['base'].append(m_base[:got])
+            t1 = time.perf_counter()
+            out.timing['load'] += t1 - t0
+            if ids:
+                cat = lambda parts, dt: np.concatenate(parts) if len(parts) > 1 else _c_arr(parts[0], dt)
+                m_mean, m_stdv = cat(cols['mean'], np.float32), cat(cols['stdv'], np.float32)
+                m_start, m_len, m_base = cat(cols['start'], np.uint64), cat(cols['length'], np.uint64), cat(cols['base'], 'S1')
+                raw_off, mev_off = np.array(raw_offs, np.int64), np.array(ev_offs, np.int64)
+                try:
+                    s_mean, s_stdv, first_empty = normalizer.event_stats_arrays(raw_parts, raw_off, m_start, m_len, mev_off)
+                except _lib.DeepModHipError:
+                    # a read the batched signal call cannot take (events covering no signal): the per-read Python path reports it
+                    lib.dm_rows_destroy(h)
+                    h = None
+                    return _prepare_batch_py(moptions, files, make_normalizer, alloc)
+                t2 = time.perf_counter()
+                out.timing['signal'] += t2 - t1
+                # alignment records: the reference's own aligner call when the binary is on PATH, else the side-car .sam files
+                f5data = {}
+                for gi, rid in enumerate(ids):
+                    if rid is None:
+                        continue
+                    if rid in f5data:
+                        print('Duplicate id', rid, id_src[gi])
+                    call = m_base[mev_off[gi]:mev_off[gi + 1]].tobytes().decode('ascii', 'replace') if moptions.get('Ref') else ''
+                    f5data[rid] = (call, gi, None, id_src[gi], (0, 0))
+                align_info = detect._alignment_lines(moptions, {'Error': out.errors}, raw_files, f5data)
+                if align_info is None:
+                    for f5k in sorted(f5data.keys()):
+                        out.errors["Cannot running aligment"].append(f5data[f5k][3])
+                else:
+                    sp_param = {'f5data': f5data, 'ref_info': {}, 'f5status': "", 'line': ""}
+                    f5align = readmap.parse_sam(moptions, {'Error': out.errors}, sp_param, align_info, f5data)
+                    recs = list(f5align.items())
+                    nrec = len(recs)
+                    seqs = readmap.read_fasta(moptions['Ref']) if moptions.get('Ref') else {}
+                    ref_bytes = _REF_BYTES.setdefault(moptions.get('Ref'), {})
+                    flag = np.zeros(nrec, np.int32); pos1 = np.zeros(nrec, np.int64); rlen = np.zeros(nrec, np.int64)
+                    cidx = np.full(nrec, -1, np.int32); ev_read = np.zeros(nrec, np.int32); skip = np.zeros(nrec, np.uint8)
+                    cig_b, seq_b = [], []
+                    for i, (qname, (mapq, fl, rname, ps, cigar, seq)) in enumerate(recs):
+                        flag[i], pos1[i], ev_read[i] = fl, ps, f5data[qname][1]
+                        cig_b.append(cigar.encode('ascii')); seq_b.append(seq.encode('ascii'))
+                        rlen[i] = len(seq_b[-1])
+                        if (not moptions.get('ConUnk', True)) and any(ch in rname for ch in '_-/:'):
+                            skip[i] = 1
+                        if rname not in contigs:
+                            contigs[rname] = len(contigs)
+                        cidx[i] = contigs[rname]
+                        if rname in seqs and rname not in ref_bytes:
+                            ref_bytes[rname] = seqs[rname].encode('ascii')
+                        if rname not in seqs:
+                            print('Fatal Error!!! cannot find the chrosome sequence %s' % rname)
+                    names = sorted(contigs, key=contigs.get)
+                    nct = len(names)
+                    ref_ptr = (ctypes.c_char_p * max(nct, 1))(*[ref_bytes.get(nm) for nm in names])
+                    ref_len = np.array([len(ref_bytes[nm]) if nm in ref_bytes else 0 for nm in names] or [0], np.int64)
+                    cig_ptr = (ctypes.c_char_p * max(nrec, 1))(*cig_b)
+                    seq_ptr = (ctypes.c_char_p * max(nrec, 1))(*seq_b)
+                    region = [mr for mr in moptions.get('region', [[None, None, None]])]
+                    any_all = any(mr[0] in ['', None] and mr[1] in ['', None] and mr[2] in ['', None] for mr in region)
+                    if any_all:
+                        region = []
+                    rg_c = np.array([(-1 if mr[0] in ['', None] else contigs.get(mr[0], 0x7fffffff)) for mr in region] or [0], np.int32)   # a contig no record of the batch names: matches nothing
+                    rg_lo = np.array([(-1 if mr[1] in ['', None] else int(mr[1])) for mr in region] or [0], np.int64)
+                    rg_hi = np.array([(-1 if mr[2] in ['', None] else int(mr[2])) for mr in region] or [0], np.int64)
+                    keep.extend([flag, pos1, rlen, cidx, ev_read, skip, cig_b, seq_b, ref_ptr, ref_len, cig_ptr, seq_ptr, mev_off, m_mean, m_stdv,
+                                 m_len, m_base, s_mean, s_stdv, first_empty, rg_c, rg_lo, rg_hi])
+                    _lib.check(lib.dm_rows_add_raw(h, nrec, flag.ctypes.data, pos1.ctypes.data, cig_ptr, seq_ptr, rlen.ctypes.data, cidx.ctypes.data,
+                                                   ev_read.ctypes.data, skip.ctypes.data, nct, ref_ptr, ref_len.ctypes.data, mev_off.ctypes.data,
+                                                   m_mean.ctypes.data, m_stdv.ctypes.data, m_len.ctypes.data, m_base.ctypes.data, s_mean.ctypes.data,
+                                                   s_stdv.ctypes.data, first_empty.ctypes.data, len(region), rg_c.ctypes.data, rg_lo.ctypes.data,
+                                                   rg_hi.ctypes.data))
+                    srcs.extend(f5data[q][3] for q, _ in recs)
+                    for nm in names:
+                        if nm in ref_bytes:
+                            out.contig_len[nm] = len(ref_bytes[nm])
+                out.timing['map+features'] += time.perf_counter() - t2
+            t0 = time.perf_counter()
+        for cf in files:
+            if cf.endswith(rawreads.RAW_SUFFIX):
+                continue
+            try:
+                pk = predstore.load_packed(cf)
+            except Exception:
+                out.errors["Cannot open container"].append(cf)
+                continue
+            t1 = time.perf_counter()
+            out.timing['load'] += t1 - t0
+            meta = pk['reads']
+            n = len(meta)
+            if n:
+                for m in meta:
+                    if m['chr'] not in contigs:
+                        contigs[m['chr']] = len(contigs)
+                arrs = [_c_arr(pk['row_off'], np.int64), _c_arr(pk['bmi_off'], np.int64), _c_arr(pk['ev_off'], np.int64), _c_arr(pk['tx'], np.float32),
+                        _c_arr(pk['refbase'], 'S1'), _c_arr(pk['readbase'], 'S1'), _c_arr(pk['refbasei'], np.int64), _c_arr(pk['evbase'], 'S1'),
+                        np.array([m['start_clip'] for m in meta], np.int64), np.array([m['end_clip'] for m in meta], np.int64),
+                        np.array([contigs[m['chr']] for m in meta], np.int32), np.array([strands_c[m['strand']] for m in meta], np.int32)]
+                keep.append(arrs)
+                _lib.check(lib.dm_rows_add_packed(h, n, *[a.ctypes.data for a in arrs]))
+                srcs.extend([cf] * n)
+            for c, ln in pk.get('contig_len', {}).items():
+                out.contig_len[c] = max(out.contig_len.get(c, 0), int(ln))
+            t0 = time.perf_counter()
+            out.timing['rows'] += t0 - t1
+        # ---- sizes, errors, then the arrays themselves (straight into the hand-over slot when alloc is given) ----
+        nreads = len(srcs)
+        info = np.zeros((max(nreads, 1), 8), np.int64)
+        mism = np.zeros((20, 4), np.int64)
+        R, T, nm = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        if lib.dm_rows_info(h, ctypes.byref(R), ctypes.byref(T), info.ctypes.data, mism.ctypes.data, 20, ctypes.byref(nm)) < 0:
+            raise _lib.DeepModHipError("dm_rows_info: " + _lib.last_error())
+        for i in range(nreads):
+            st = int(info[i, 0])
+            if st in _ROWS_ERRORS:
+                out.errors[_ROWS_ERRORS[st]].append(srcs[i])
+            elif st == 3:
+                print("Errorfast5 " + srcs[i])
+                print('match-Error!!! no first and/or last match', srcs[i])
+        for j in range(min(int(nm.value), 20)):
+            print('Error Does not match: read %d of the batch (%s), table row %d, event %d, %d bases differ'
+                  % (mism[j, 0], srcs[int(mism[j, 0])], mism[j, 1], mism[j, 2], mism[j, 3]))
+        R, T = int(R.value), int(T.value)
+        ok = info[:nreads, 0] == 0
+        out.n_reads = int(ok.sum())
+        out.n_windows = int(info[:nreads, 3][ok].sum())
+        out.n_rows = R
+        if R:
+            if alloc is not None:
+                out.rows, out.pos, out.flags = alloc(R, T)
+            else:
+                out.rows, out.pos, out.flags = np.empty((R, 7), np.float32), np.empty(T, np.int64), np.empty(T, np.uint8)
+            names = sorted(contigs, key=contigs.get)
+            rank = np.empty(max(len(names), 1), np.int32)
+            rank[np.argsort(np.array(names, dtype=object), kind='stable') if names else []] = np.arange(len(names), dtype=np.int32)
+            clen = np.zeros(max(len(names), 1), np.int64)
+            groups = np.zeros((2 * max(len(names), 1), 6), np.int64)
+            in_range = ctypes.c_int32(1)
+            ng = lib.dm_rows_emit(h, rank.ctypes.data, out.rows.ctypes.data, out.pos.ctypes.data, out.flags.ctypes.data, groups.ctypes.data,
+                                  len(groups), clen.ctypes.data, len(clen), ctypes.byref(in_range))
+            if ng < 0:
+                raise _lib.DeepModHipError("dm_rows_emit: " + _lib.last_error())
+            out.groups = [(names[int(g[0])], '+-'[int(g[1])], int(g[2]), int(g[3]), int(g[4]), int(g[5])) for g in groups[:ng]]
+            for i, nmn in enumerate(names):
+                if clen[i] > out.contig_len.get(nmn, 0):
+                    out.contig_len[nmn] = int(clen[i])        # lower bound when no reference length is known
+            out.f32 = not bool(in_range.value)
+        out.timing['rows'] += time.perf_counter() - t0
+        return out
+    finally:
+        if h:
+            lib.dm_rows_destroy(h)
+        del keep
+
+
 def prepare_batch(moptions, files: List[str], make_normalizer=None, alloc=None) -> Prepared:
     """Host side of one worker batch (the reference's mDetect1 up to the call of mPredict1, myDetect.py:392-465, :488-715):
     raw containers go through signal normalisation, alignment records, dm_map_read and get_Feature; feature containers
-    enter at the prediction step."""
+    enter at the prediction step.  Default: the compiled path (_prepare_batch_c); moptions['rows_in_c'] = False (or
+    DEEPMOD_ROWS_IN_C=0) selects the per-read Python restatement."""
+    if moptions.get('rows_in_c', os.environ.get('DEEPMOD_ROWS_IN_C', '1') != '0'):
+        return _prepare_batch_c(moptions, files, make_normalizer, alloc)
+    return _prepare_batch_py(moptions, files, make_normalizer, alloc)
+
+
+def _prepare_batch_py(moptions, files: List[str], make_normalizer=None, alloc=None) -> Prepared:
+    """The per-read Python / numpy path (rounds 1-2): kept as the restatement the compiled path is tested against."""
     out = _PreparedBuilder()
     out.files = list(files)
     base = moptions['Base']
@@ -365,6 +605,26 @@ class RemoteSignalNormalizer:
         keys = ("mshift", "mscale", "read_med", "read_mad", "lower_lim", "upper_lim")
         return [(mean[ev_off[i]:ev_off[i + 1]], stdv[ev_off[i]:ev_off[i + 1]], dict(zip(keys, norm6[i].tolist())), int(first_empty[i]))
                 for i in range(n)]
+
+    def event_stats_arrays(self, raw_parts, raw_off, ev_start, ev_length, ev_off):
+        """Same request as event_stats_batch, from arrays that are already back to back (see signal.SignalNormalizer.event_stats_arrays)."""
+        from . import _lib
+        n = len(raw_off) - 1
+        n_raw, n_ev = int(raw_off[-1]), int(ev_off[-1])
+        o = _sig_layout(n, n_raw, n_ev)
+        self._ensure(o['end'])
+        mm = self.mm
+        np.concatenate([np.asarray(p) for p in raw_parts], out=np.frombuffer(mm, np.int16, n_raw, o['raw']), casting='same_kind')
+        np.frombuffer(mm, np.int64, n + 1, o['raw_off'])[:] = raw_off
+        np.frombuffer(mm, np.int64, n + 1, o['ev_off'])[:] = ev_off
+        np.frombuffer(mm, np.uint64, n_ev, o['ev_start'])[:] = ev_start
+        np.frombuffer(mm, np.uint64, n_ev, o['ev_length'])[:] = ev_length
+        self.requests.put((self.wid, self.path, self.size, n, n_raw, n_ev))
+        err = self.answers.get()
+        if err is not None:
+            raise _lib.DeepModHipError(err)
+        return (np.frombuffer(mm, np.float32, n_ev, o['mean']).copy(), np.frombuffer(mm, np.float32, n_ev, o['stdv']).copy(),
+                np.frombuffer(mm, np.int64, n, o['first_empty']).copy())
 
     def event_stats(self, raw, ev_start, ev_length, want_signal: bool = False):
         if want_signal:

@@ -303,6 +303,43 @@ int dm_map_read(int flag, int64_t pos1, const char* cigar, const char* readseq, 
                 const char* refseq, int64_t refseq_len, int64_t n_events, char* refbase, char* readbase,
                 uint64_t* refbasei, uint64_t* readbasei, int64_t cap_rows, int64_t* info);
 
+/* ---- one worker batch of reads -> the device-ready arrays of the streaming detect (host code) ------------------------------
+ * What the streaming worker uploads per batch: feature rows [R][7] fp32 (the reads' matrices back to back, 100 zero rows of
+ * padding on both sides of every read - myDetect.py:850-851), per row a reference position and a flag byte (dm_summary_add_classified),
+ * and "extra" (position, flag) pairs of table rows that own no window.  Replaces, per batch instead of per read:
+ *   dm_events_merge     getEvent, Albacore-2 'simple' branch                           myDetect.py:237-251
+ *   dm_rows_add_raw     handle_record's filters + alignment walk + get_Feature         myDetect.py:497-713, :839-903
+ *   dm_rows_add_packed  the reads of a feature container (arguments of mPredict1)      myDetect.py:715
+ *   dm_rows_info / dm_rows_emit   window <-> base association and per-base flags        myDetect.py:794-803, :824-833, :1089-1100
+ * Per-read status codes (read_info[i][0]): */
+#define DM_ROWS_OK 0
+#define DM_ROWS_LESS_EVENT 1      /* fewer than 50 aligned events (:702-705) */
+#define DM_ROWS_INDEX_ERROR 2     /* fewer aligned table rows than aligned events (the reference raises IndexError) */
+#define DM_ROWS_NO_MATCH 3        /* no matching base (:617-622) */
+#define DM_ROWS_CIGAR_ERROR 4
+#define DM_ROWS_FILTERED 5        /* region filter / skipped by the caller */
+#define DM_ROWS_NO_REFERENCE 6
+#define DM_ROWS_NOT_MATCHING 7    /* raw reads: event bases differ from the table's read bases (:868-874) */
+#define DM_ROWS_INFO 8            /* int64 per read: status, contig, strand (0 '+', 1 '-'), windows, rows, table rows, mismatches, extras */
+typedef struct dm_rowsbatch dm_rowsbatch;
+int64_t dm_events_merge(int64_t n_reads, const int64_t* ev_off, const double* mean, const double* stdv, const uint64_t* start,
+                        const uint64_t* length, const uint32_t* model_state, int32_t ms_width, const int64_t* move, int64_t* mev_off,
+                        float* m_mean, float* m_stdv, uint64_t* m_start, uint64_t* m_length, char* m_base);
+dm_rowsbatch* dm_rows_create(char base);
+void dm_rows_destroy(dm_rowsbatch* h);
+int dm_rows_add_packed(dm_rowsbatch* h, int64_t n_reads, const int64_t* row_off, const int64_t* bmi_off, const int64_t* ev_off,
+                       const float* tx, const char* refbase, const char* readbase, const int64_t* refbasei, const char* evbase,
+                       const int64_t* start_clip, const int64_t* end_clip, const int32_t* contig, const int32_t* strand);
+int dm_rows_add_raw(dm_rowsbatch* h, int64_t n_reads, const int32_t* flag, const int64_t* pos1, const char* const* cigar,
+                    const char* const* readseq, const int64_t* readseq_len, const int32_t* contig, const int32_t* ev_read,
+                    const uint8_t* skip, int32_t n_contigs, const char* const* refseq, const int64_t* refseq_len,
+                    const int64_t* mev_off, const float* m_mean, const float* m_stdv, const uint64_t* m_length, const char* m_base,
+                    const float* s_mean, const float* s_stdv, const int64_t* first_empty, int32_t n_region,
+                    const int32_t* region_contig, const int64_t* region_lo, const int64_t* region_hi);
+int64_t dm_rows_info(dm_rowsbatch* h, int64_t* n_rows, int64_t* n_pos, int64_t* read_info, int64_t* mism, int64_t cap_mism, int64_t* n_mism);
+int64_t dm_rows_emit(dm_rowsbatch* h, const int32_t* contig_rank, float* rows, int64_t* pos, uint8_t* flags, int64_t* groups,
+                     int64_t cap_groups, int64_t* contig_len, int64_t n_contig_len, int32_t* in_range);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,13 +200,19 @@ def test_npzmap_views_equal_numpy_load(tmp_path):
     arrays = {'f32': rng.normal(size=(1000, 7)).astype(np.float32), 'i64': rng.integers(0, 1 << 40, 333), 'empty': np.zeros(0, np.int16),
               'u5': np.array(['ACGTA', 'TTTTT', 'GGCAA']), 's1': np.frombuffer(b'ACGT-', 'S1'), 'scalar': np.array(2),
               'meta': np.array('{"reads": [1, 2]}'), 'fortran': np.asfortranarray(rng.normal(size=(5, 4)))}
-    for name, saver in (('stored.npz', np.savez), ('deflated.npz', np.savez_compressed)):
+    for name, saver in (('aligned.npz', npzmap.savez_aligned), ('stored.npz', np.savez), ('deflated.npz', np.savez_compressed)):
         path = str(tmp_path / name)
         saver(path, **arrays)
         got = npzmap.load(path)
         assert sorted(got) == sorted(arrays)
         for k, v in arrays.items():
             assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), (name, k)
+            assert got[k].ctypes.data % max(v.dtype.alignment, 1) == 0, (name, k)      # never a misaligned pointer for the C ABI
         assert str(got['meta']) == str(arrays['meta']) and int(got['scalar']) == 2
-    stored = npzmap.load(str(tmp_path / 'stored.npz'))
-    assert not stored['f32'].flags.writeable                 # views into a read-only mapping
+    # the package's own writer aligns every member to 64 bytes: zero-copy views into a read-only mapping (numpy.savez members
+    # start wherever the zip header ends: those are copied when misaligned); numpy.load reads the aligned file as well
+    aligned = npzmap.load(str(tmp_path / 'aligned.npz'))
+    for k in ('f32', 'i64', 'fortran'):
+        assert not aligned[k].flags.writeable and aligned[k].ctypes.data % 64 == 0, k
+    z = np.load(str(tmp_path / 'aligned.npz'))
+    assert all(np.array_equal(z[k], v) for k, v in arrays.items())

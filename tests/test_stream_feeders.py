@@ -157,3 +157,86 @@ def test_remote_signal_normalizer_protocol(tmp_path):
     requests.put(None)
     th.join(timeout=5)
     norm.close()
+
+
+class _OracleNormalizer:
+    """TEST stand-in for the device signal stage (deepmod_amd.signal.SignalNormalizer): both call forms of the interface, served
+    from oracle/signal_oracle.py, so that the raw path of prepare_batch runs on a CPU box."""
+
+    def _one(self, raw, st, ln):
+        from oracle import signal_oracle
+        from deepmod_amd import rawreads
+        ev = np.zeros(len(st), dtype=rawreads.EVENT_DTYPE)
+        ev['start'], ev['length'] = st, ln
+        sig, norm = signal_oracle.mnormalized(raw, ev)
+        mean, stdv, fe = signal_oracle.event_stats(sig, ev)
+        return mean, stdv, norm, fe
+
+    def event_stats_batch(self, reads):
+        return [self._one(*r) for r in reads]
+
+    def event_stats_arrays(self, raw_parts, raw_off, ev_start, ev_length, ev_off):
+        raw = np.concatenate(raw_parts)
+        n = len(raw_off) - 1
+        mean, stdv, fe = np.empty(len(ev_start), np.float32), np.empty(len(ev_start), np.float32), np.empty(n, np.int64)
+        for r in range(n):
+            m, s, _, f = self._one(raw[raw_off[r]:raw_off[r + 1]], ev_start[ev_off[r]:ev_off[r + 1]], ev_length[ev_off[r]:ev_off[r + 1]])
+            mean[ev_off[r]:ev_off[r + 1]], stdv[ev_off[r]:ev_off[r + 1]], fe[r] = m, s, f
+        return mean, stdv, fe
+
+
+def _same_batch(a, b):
+    assert a.n_rows == b.n_rows and a.n_reads == b.n_reads and a.n_windows == b.n_windows
+    assert a.groups == b.groups, (a.groups, b.groups)
+    used = {g[0] for g in a.groups}          # (a contig that no surviving read names never gets counters: its length is not compared)
+    assert {c: a.contig_len[c] for c in used} == {c: b.contig_len[c] for c in used}
+    assert np.array_equal(a.rows, b.rows) and np.array_equal(a.pos, b.pos) and np.array_equal(a.flags, b.flags)
+    assert a.f32 == b.f32
+    norm = lambda e: {k.split(':')[0]: sorted(v) for k, v in e.items() if v}
+    assert norm(a.errors) == norm(b.errors), (dict(a.errors), dict(b.errors))
+
+
+def test_compiled_batch_equals_python_batch_on_feature_and_packed_containers(tmp_path):
+    """dm_rows_add_packed + dm_rows_info + dm_rows_emit against the per-read numpy path (stream._prepare_batch_py): feature
+    containers of both formats, two contigs, both strands, a read too short to be called, deletions (extra rows)."""
+    from deepmod_amd import predstore
+    a = synth_reads.write_synthetic_run(str(tmp_path / 'a'), n_reads=9, reads_per_file=3, genome_len=6000, seed=3, chrom='chrB',
+                                        min_len=120, max_len=400)
+    b = synth_reads.write_synthetic_run(str(tmp_path / 'b'), n_reads=6, reads_per_file=3, genome_len=5000, seed=4, chrom='chrA',
+                                        min_len=120, max_len=400)
+    packed = []
+    for i, f in enumerate(b):
+        p = str(tmp_path / 'b' / ('packed_%d%s' % (i, predstore.CONTAINER_SUFFIX)))
+        predstore.save_packed_container(p, predstore.load_feature_container(f), {'chrA': 5000})
+        os.remove(f)
+        packed.append(p)
+    short = synth_reads.write_synthetic_run(str(tmp_path / 'c'), n_reads=2, reads_per_file=2, genome_len=3000, seed=5, chrom='chrB',
+                                            min_len=30, max_len=40)
+    files = a + packed + short
+    for base in 'CA':
+        mo = {'Base': base, 'outFolder': str(tmp_path), 'fnum': 7, 'hidden': 100, 'windowsize': 21}
+        got = stream._prepare_batch_c(mo, files)
+        ref = stream._prepare_batch_py(mo, files)
+        _same_batch(got, ref)
+        assert got.n_reads == 15 and len(got.errors['Less Event']) == 2 and len(got.groups) >= 3
+        assert (got.flags[got.n_rows:] & 1).all() and len(got.pos) > got.n_rows        # extras exist and are all of the wanted base
+
+
+def test_compiled_batch_equals_python_batch_on_raw_containers(tmp_path):
+    """dm_events_merge + dm_rows_add_raw (alignment walk, get_Feature rows) against rawreads.getEvent / readmap.map_records /
+    features.get_Feature / stream.rows_from_reads, the signal stage served by the oracle on both sides."""
+    files, fasta = synth_reads.write_synthetic_raw_run(str(tmp_path / 'in'), n_reads=14, reads_per_file=5, genome_len=30000, seed=6,
+                                                       chrom='chrS', min_len=300, max_len=1200)
+    mo = {'Base': 'C', 'outFolder': str(tmp_path), 'fnum': 7, 'hidden': 100, 'windowsize': 21, 'Ref': fasta, 'alignStr': 'minimap2',
+          'region': [[None, None, None]], 'ConUnk': True, 'SignalGroup': 'simple', 'outLevel': 3}
+    norm = _OracleNormalizer()
+    got = stream._prepare_batch_c(dict(mo), files, lambda: norm)
+    ref = stream._prepare_batch_py(dict(mo), files, lambda: norm)
+    _same_batch(got, ref)
+    assert got.n_reads >= 12 and got.n_windows > 5000 and got.rows[:, :4].sum() > 0 and got.rows[:, 4:].any()
+    # a region filter that keeps the first half of the contig only, and a region on another contig (nothing passes)
+    for region, expect_some in (([['chrS', None, 15000]], True), ([['chrT', None, None]], False)):
+        g2 = stream._prepare_batch_c(dict(mo, region=region), files, lambda: norm)
+        r2 = stream._prepare_batch_py(dict(mo, region=region), files, lambda: norm)
+        _same_batch(g2, r2)
+        assert (g2.n_reads > 0) == expect_some and g2.n_reads < got.n_reads

@@ -81,3 +81,25 @@ def write_synthetic_checkpoint(prefix: str, seed: int = 7, scale: float = 1.0) -
     w = synthetic_weights(seed, scale)
     tfbundle.write_bundle(prefix, w, layout=REAL_LAYOUT, total_size=REAL_DATA_SIZE)
     return w
+
+
+def write_synthetic_data_for_index(index_path: str, prefix: str, seed: int = 7, scale: float = 1.0) -> Dict[str, np.ndarray]:
+    """A shipped model directory rebuilt around its REAL `.index` (copied next to `prefix`): a `.data-00000-of-00001` of the size
+    and byte layout that index describes (Adam slots and all), holding synthetic weights where the model's variables live and
+    zeros elsewhere.  What a user who has the real shard does with --modfile is then exercised byte for byte except the values."""
+    import os
+    import shutil
+    os.makedirs(os.path.dirname(prefix) or '.', exist_ok=True)
+    shutil.copyfile(index_path, prefix + ".index")
+    entries = tfbundle.read_index(prefix + ".index")
+    w = synthetic_weights(seed, scale)
+    total = max(e.offset + e.size for e in entries.values())
+    blob = np.zeros(total, np.uint8)
+    for name, arr in w.items():
+        e = entries[name]
+        if tuple(e.shape) != arr.shape or e.size != arr.nbytes:
+            raise ValueError("variable %s: the index says %s, the model wants %s" % (name, e.shape, arr.shape))
+        blob[e.offset:e.offset + e.size] = np.frombuffer(np.ascontiguousarray(arr, "<f4").tobytes(), np.uint8)
+    with open(tfbundle.data_path(prefix), "wb") as fh:
+        fh.write(blob.tobytes())
+    return w

@@ -41,6 +41,7 @@ SIGNATURES = [
     ("dm_model_get_info", _c.c_int, [_vp, _c.c_int, _c.POINTER(_i64)]),
     ("dm_predict_windows", _c.c_int, [_vp, _vp, _i64, _vp, _vp]),
     ("dm_predict_read", _c.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    ("dm_predict_read_at", _c.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     ("dm_model_sync", _c.c_int, [_vp]),
     ("dm_profile_reset", _c.c_int, [_vp]),
     ("dm_profile_get", _c.c_int, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_i64), _c.POINTER(_i64)]),
@@ -90,8 +91,8 @@ SIGNATURES = [
     ("dm_rows_add_packed", _c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("dm_rows_add_raw", _c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _c.c_int32, _vp, _vp, _vp]),
-    ("dm_rows_info", _i64, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _vp, _vp, _i64, _c.POINTER(_i64)]),
-    ("dm_rows_emit", _i64, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32)]),
+    ("dm_rows_info", _i64, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64), _vp, _vp, _i64, _c.POINTER(_i64)]),
+    ("dm_rows_emit", _i64, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32)]),
 ]
 
 

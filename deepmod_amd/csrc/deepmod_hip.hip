@@ -596,7 +596,7 @@ int ensure_f16lm(dm_model* m) {
 #endif
 
 // launch on device-resident buffers
-int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, float* d_prob, uint8_t* d_cls) {
+int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, float* d_prob, uint8_t* d_cls, const int* d_widx = nullptr) {
     if (n <= 0) return DM_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->profile) {
@@ -630,6 +630,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         p.bout1 = m->bout[1];
         p.x = d_x;
         p.xstride = xstride;
+        p.widx = d_widx;
         p.n = n;
         p.ntiles = int((n + TILE_M - 1) / TILE_M);
         int rcp = ensure_plogit(m, p.ntiles);
@@ -690,6 +691,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         p.bout1 = m->bout[1];
         p.x = d_x;
         p.xstride = xstride;
+        p.widx = d_widx;
         p.n = n;
         p.prob = d_prob;
         p.cls = d_cls;
@@ -1008,6 +1010,70 @@ int dm_predict_read(dm_model* m, const float* rows, int64_t m_rows, int64_t firs
     // host rows: ship only the rows this call needs
     const float* base = rows + (first - DM_WINDOW / 2) * DM_NFEAT;
     return predict_common(m, base, DM_NFEAT, (count + DM_WINDOW - 1) * DM_NFEAT, count, prob, cls, false);
+}
+
+// Classify `count` windows of a feature-row matrix picked by their CENTRE rows: window i = rows[centre[i] - 10 .. centre[i] + 10].
+// What the streaming worker calls: only windows centred on a base of interest can reach the BED (sum_handler tests refbase == Base
+// before it looks at mod_pred, myDetect.py:1091-1100), so the other ~3/4 of a read's windows are never computed.  Everything
+// device-resident: queued on the model's stream (DM_OPT_ASYNC), else synchronous.  Host arrays are staged through temporaries.
+int dm_predict_read_at(dm_model* m, const float* rows, int64_t m_rows, const int32_t* centre, int64_t count, float* prob, uint8_t* cls) {
+    if (!m) return fail(DM_EINVAL, "null model");
+    if (count < 0 || m_rows < 0) return fail(DM_EINVAL, "negative count");
+    if (count == 0) return DM_OK;
+    if (!rows || !centre) return fail(DM_EINVAL, "null input");
+    if (m_rows < DM_WINDOW) return fail(DM_EINVAL, "%lld feature rows hold no window", (long long)m_rows);
+    if (m->precision == DM_PREC_F16X3_LM) return fail(DM_EINVAL, "dm_predict_read_at: not built into the layer-major experiment kernel");
+    HIP_TRY(hipSetDevice(m->device));
+    const bool rd = is_device_ptr(rows), cd = is_device_ptr(centre), pd = prob ? is_device_ptr(prob) : true, kd = cls ? is_device_ptr(cls) : true;
+    if (rd && cd && pd && kd) {
+        int rc = launch_bilstm(m, rows - (DM_WINDOW / 2) * DM_NFEAT, DM_NFEAT, count, prob, cls, centre);
+        if (rc) return rc;
+        return m->async ? DM_OK : sync_and_check(m);
+    }
+    // host arrays (tests, small callers): the centres are checked, everything goes through temporaries, synchronous
+    if (!cd)
+        for (int64_t i = 0; i < count; ++i)
+            if (centre[i] < DM_WINDOW / 2 || centre[i] >= m_rows - DM_WINDOW / 2)
+                return fail(DM_EINVAL, "window %lld: centre row %d +-10 outside the %lld feature rows", (long long)i, centre[i], (long long)m_rows);
+    float* d_rows = nullptr;
+    int* d_centre = nullptr;
+    float* d_prob = nullptr;
+    uint8_t* d_cls = nullptr;
+    int rc = DM_OK;
+    auto cleanup = [&]() {
+        if (!rd) (void)hipFree(d_rows);
+        if (!cd) (void)hipFree(d_centre);
+        if (prob && !pd) (void)hipFree(d_prob);
+        if (cls && !kd) (void)hipFree(d_cls);
+    };
+#define DM_TRY_CLEAN(expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) {                                                                              \
+            cleanup();                                                                                       \
+            return fail(DM_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(_e));                          \
+        }                                                                                                    \
+    } while (0)
+    if (!rd) {
+        DM_TRY_CLEAN(hipMalloc(&d_rows, sizeof(float) * size_t(m_rows) * DM_NFEAT));
+        DM_TRY_CLEAN(hipMemcpyAsync(d_rows, rows, sizeof(float) * size_t(m_rows) * DM_NFEAT, hipMemcpyHostToDevice, m->stream));
+    } else d_rows = const_cast<float*>(rows);
+    if (!cd) {
+        DM_TRY_CLEAN(hipMalloc(&d_centre, sizeof(int) * size_t(count)));
+        DM_TRY_CLEAN(hipMemcpyAsync(d_centre, centre, sizeof(int) * size_t(count), hipMemcpyHostToDevice, m->stream));
+    } else d_centre = const_cast<int*>(centre);
+    if (prob && !pd) DM_TRY_CLEAN(hipMalloc(&d_prob, sizeof(float) * 2 * size_t(count)));
+    else d_prob = prob;
+    if (cls && !kd) DM_TRY_CLEAN(hipMalloc(&d_cls, size_t(count)));
+    else d_cls = cls;
+    rc = launch_bilstm(m, d_rows - (DM_WINDOW / 2) * DM_NFEAT, DM_NFEAT, count, d_prob, d_cls, d_centre);
+    if (rc == DM_OK && prob && !pd) DM_TRY_CLEAN(hipMemcpyAsync(prob, d_prob, sizeof(float) * 2 * size_t(count), hipMemcpyDeviceToHost, m->stream));
+    if (rc == DM_OK && cls && !kd) DM_TRY_CLEAN(hipMemcpyAsync(cls, d_cls, size_t(count), hipMemcpyDeviceToHost, m->stream));
+    if (rc == DM_OK) rc = sync_and_check(m);
+    else (void)hipStreamSynchronize(m->stream);
+    cleanup();
+#undef DM_TRY_CLEAN
+    return rc;
 }
 
 // debug builds (-DDM_TIMING): copy the per-wave section cycle counters [grid][waves][8]; returns element count

@@ -575,6 +575,9 @@ def _run_streaming_detect(moptions, ctx, pmanager, items, ngpu):
     return ledger, stats
 
 
+_BASE_OF_RUN = ['?']
+
+
 def _print_stream_stats(stats, wall):
     tot = defaultdict(float)
     for st in stats:
@@ -583,6 +586,10 @@ def _print_stream_stats(stats, wall):
     rows = tot['windows']
     print('Streaming detect: %d reads, %d base-positions classified on %d GPU(s) in %.1f s = %.3g base-positions/s'
           % (tot['reads'], rows, len(stats), wall, rows / max(wall, 1e-9)))
+    if tot.get('submit_classified'):
+        print('\twindows run through the classifier: %d of those %d base-positions (only a window centred on base %s can reach the BED, '
+              'myDetect.py:1091; --storePred 1 classifies every base as the reference does) = %.3g windows/s'
+              % (tot['submit_classified'], rows, _BASE_OF_RUN[0], tot['submit_classified'] / max(wall, 1e-9)))
     host = {k[5:]: v for k, v in tot.items() if k.startswith('prep_')}
     busy = sum(host.values()) + tot['submit']
     parts = ['%s %.0f%%' % (k, 100 * v / max(busy, 1e-9)) for k, v in sorted(host.items(), key=lambda kv: -kv[1])]
@@ -638,6 +645,7 @@ def mDetect_manager(moptions):
         items = plan_batches(files, moptions['files_per_thread'])
         streamed = not moptions.get('storePred', 0)
         if streamed:
+            _BASE_OF_RUN[0] = moptions['Base']
             ledger, stats = _run_streaming_detect(moptions, ctx, pmanager, items, ngpu)
             _print_stream_stats(stats, time.time() - t0)
         else:

@@ -188,6 +188,27 @@ class BiLSTMModel:
         """dm_predict_read on raw device addresses (staging buffers of the streaming worker)."""
         _lib.check(self._lib.dm_predict_read(self._h, rows_ptr, m_rows, first, count, prob_ptr, cls_ptr))
 
+    def predict_rows_at_device(self, rows_ptr: int, m_rows: int, centre_ptr: int, count: int, cls_ptr: int, prob_ptr=None):
+        """dm_predict_read_at on raw device addresses: only the windows centred on the given rows."""
+        _lib.check(self._lib.dm_predict_read_at(self._h, rows_ptr, m_rows, centre_ptr, count, prob_ptr, cls_ptr))
+
+    def predict_read_at(self, rows, centres, prob=None, cls=None, want_prob: bool = True):
+        """Classify the windows centred on rows[centres[i]] of a feature matrix rows float[m,7] (numpy or DeviceArray)."""
+        if isinstance(rows, DeviceArray):
+            m = rows.shape[0]
+        else:
+            rows = np.ascontiguousarray(rows, dtype=np.float32)
+            m = rows.shape[0]
+        if not isinstance(centres, DeviceArray):
+            centres = np.ascontiguousarray(centres, dtype=np.int32)
+        count = centres.shape[0]
+        if cls is None:
+            cls = np.empty(count, np.uint8)
+        if prob is None and want_prob:
+            prob = np.empty((count, 2), np.float32)
+        _lib.check(self._lib.dm_predict_read_at(self._h, _ptr(rows), m, _ptr(centres), count, _ptr(prob), _ptr(cls)))
+        return prob, cls
+
     # -- inference ------------------------------------------------------------------------
     def predict_windows(self, x, prob=None, cls=None, want_prob: bool = True):
         """x: float[n,21,7] numpy (any float dtype; cast to fp32 like the TF placeholder feed) or a

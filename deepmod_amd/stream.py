@@ -39,14 +39,18 @@ HALF = 10          # windowsize // 2
 
 class Prepared:
     """One worker batch, ready for the device.  Rows of the reads are concatenated, reads grouped by (contig, strand)."""
-    __slots__ = ('rows', 'pos', 'flags', 'n_rows', 'groups', 'n_windows', 'n_reads', 'errors', 'contig_len', 'timing', 'files', 'on_done', 'f32')
+    __slots__ = ('rows', 'pos', 'flags', 'n_rows', 'groups', 'n_windows', 'n_reads', 'errors', 'contig_len', 'timing', 'files', 'on_done', 'f32', 'sel')
 
     def __init__(self):
         self.rows = np.zeros((0, 7), np.float32)
         self.pos = np.zeros(0, np.int64)          # [n_rows classified rows | extra rows]
         self.flags = np.zeros(0, np.uint8)
         self.n_rows = 0
-        self.groups: List[Tuple[str, str, int, int, int, int]] = []   # (chr, strand, row_lo, row_hi, extra_lo, extra_hi)
+        self.groups: List[Tuple] = []   # (chr, strand, row_lo, row_hi, extra_lo, extra_hi[, sel_lo, sel_hi])
+        # compact form (the compiled path's default): sel = int32 feature-row indices of the windows centred on a base of interest -
+        # the only ones whose class can reach the BED (myDetect.py:1091); pos / flags then hold [len(sel) | extras] entries and
+        # groups carry (sel_lo, sel_hi).  None: classic form, pos / flags hold one entry per feature row and every window is classified.
+        self.sel = None
         self.n_windows = 0
         self.n_reads = 0
         self.errors: Dict[str, List[str]] = defaultdict(list)
@@ -381,9 +385,11 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
         nreads = len(srcs)
         info = np.zeros((max(nreads, 1), 8), np.int64)
         mism = np.zeros((20, 4), np.int64)
-        R, T, nm = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-        if lib.dm_rows_info(h, ctypes.byref(R), ctypes.byref(T), info.ctypes.data, mism.ctypes.data, 20, ctypes.byref(nm)) < 0:
+        R, T, S, nm = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        if lib.dm_rows_info(h, ctypes.byref(R), ctypes.byref(T), ctypes.byref(S), info.ctypes.data, mism.ctypes.data, 20, ctypes.byref(nm)) < 0:
             raise _lib.DeepModHipError("dm_rows_info: " + _lib.last_error())
+        # compact form unless the caller wants every window classified (moptions['select_base'] = False / DEEPMOD_SELECT_BASE=0)
+        compact = bool(moptions.get('select_base', os.environ.get('DEEPMOD_SELECT_BASE', '1') != '0'))
         for i in range(nreads):
             st = int(info[i, 0])
             if st in _ROWS_ERRORS:
@@ -394,27 +400,34 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
         for j in range(min(int(nm.value), 20)):
             print('Error Does not match: read %d of the batch (%s), table row %d, event %d, %d bases differ'
                   % (mism[j, 0], srcs[int(mism[j, 0])], mism[j, 1], mism[j, 2], mism[j, 3]))
-        R, T = int(R.value), int(T.value)
+        R, T, S = int(R.value), int(T.value), int(S.value)
+        if compact:
+            T = S + (T - R)                 # [S windows on a base of interest | extras]
         ok = info[:nreads, 0] == 0
         out.n_reads = int(ok.sum())
         out.n_windows = int(info[:nreads, 3][ok].sum())
         out.n_rows = R
         if R:
             if alloc is not None:
-                out.rows, out.pos, out.flags = alloc(R, T)
+                got = alloc(R, T, S) if compact else alloc(R, T)
+                out.rows, out.pos, out.flags = got[:3]
+                out.sel = (got[3] if S else np.zeros(0, np.int32)) if compact else None
             else:
                 out.rows, out.pos, out.flags = np.empty((R, 7), np.float32), np.empty(T, np.int64), np.empty(T, np.uint8)
+                out.sel = np.empty(S, np.int32) if compact else None
             names = sorted(contigs, key=contigs.get)
             rank = np.empty(max(len(names), 1), np.int32)
             rank[np.argsort(np.array(names, dtype=object), kind='stable') if names else []] = np.arange(len(names), dtype=np.int32)
             clen = np.zeros(max(len(names), 1), np.int64)
-            groups = np.zeros((2 * max(len(names), 1), 6), np.int64)
+            groups = np.zeros((2 * max(len(names), 1), 8), np.int64)
             in_range = ctypes.c_int32(1)
-            ng = lib.dm_rows_emit(h, rank.ctypes.data, out.rows.ctypes.data, out.pos.ctypes.data, out.flags.ctypes.data, groups.ctypes.data,
+            sel_dummy = np.zeros(1, np.int32)
+            sel_ptr = (out.sel.ctypes.data if S else sel_dummy.ctypes.data) if compact else None
+            ng = lib.dm_rows_emit(h, rank.ctypes.data, out.rows.ctypes.data, sel_ptr, out.pos.ctypes.data, out.flags.ctypes.data, groups.ctypes.data,
                                   len(groups), clen.ctypes.data, len(clen), ctypes.byref(in_range))
             if ng < 0:
                 raise _lib.DeepModHipError("dm_rows_emit: " + _lib.last_error())
-            out.groups = [(names[int(g[0])], '+-'[int(g[1])], int(g[2]), int(g[3]), int(g[4]), int(g[5])) for g in groups[:ng]]
+            out.groups = [(names[int(g[0])], '+-'[int(g[1])]) + tuple(int(v) for v in (g[2:8] if compact else g[2:6])) for g in groups[:ng]]
             for i, nmn in enumerate(names):
                 if clen[i] > out.contig_len.get(nmn, 0):
                     out.contig_len[nmn] = int(clen[i])        # lower bound when no reference length is known
@@ -493,16 +506,20 @@ def _prepare_batch_py(moptions, files: List[str], make_normalizer=None, alloc=No
 _ALIGN = 256
 
 
-def _shm_layout(n_rows: int, n_pos: int):
+def _shm_layout(n_rows: int, n_pos: int, n_sel: int = 0):
+    """byte offsets of [rows f32[n_rows][7] | pos i64[n_pos] | flags u8[n_pos] | sel i32[n_sel]] -> (o_pos, o_flags, end, o_sel)"""
     o_pos = -(-n_rows * 28 // _ALIGN) * _ALIGN
     o_flags = o_pos + -(-n_pos * 8 // _ALIGN) * _ALIGN
-    return o_pos, o_flags, o_flags + max(n_pos, 1)
+    o_sel = o_flags + -(-max(n_pos, 1) // _ALIGN) * _ALIGN
+    end = o_sel + 4 * n_sel if n_sel else o_flags + max(n_pos, 1)
+    return o_pos, o_flags, end, o_sel
 
 
-def _shm_views(buf, n_rows: int, n_pos: int):
-    o_pos, o_flags, _ = _shm_layout(n_rows, n_pos)
-    return (np.frombuffer(buf, np.float32, n_rows * 7, 0).reshape(n_rows, 7), np.frombuffer(buf, np.int64, n_pos, o_pos),
-            np.frombuffer(buf, np.uint8, n_pos, o_flags))
+def _shm_views(buf, n_rows: int, n_pos: int, n_sel: int = 0):
+    o_pos, o_flags, _, o_sel = _shm_layout(n_rows, n_pos, n_sel)
+    out = (np.frombuffer(buf, np.float32, n_rows * 7, 0).reshape(n_rows, 7), np.frombuffer(buf, np.int64, n_pos, o_pos),
+           np.frombuffer(buf, np.uint8, n_pos, o_flags))
+    return out + (np.frombuffer(buf, np.int32, n_sel, o_sel),) if n_sel else out
 
 
 def usable_cpus() -> int:
@@ -739,24 +756,25 @@ def feeder_process_main(moptions, work, ready, device: int, shm_dir: str, wid: i
             seq += 1
             holder = {}
 
-            def alloc(n_rows, n_pos):
-                size = _shm_layout(n_rows, n_pos)[2]
+            def alloc(n_rows, n_pos, n_sel=0):
+                size = _shm_layout(n_rows, n_pos, n_sel)[2]
                 if free_slots is not None and size <= slot_bytes:
                     holder['slot'] = free_slots.get()                    # blocks while the device queue holds every slot
-                    return _shm_views(slot_map(holder['slot']), n_rows, n_pos)
+                    return _shm_views(slot_map(holder['slot']), n_rows, n_pos, n_sel)
                 fd = os.open(path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
                 try:
                     os.ftruncate(fd, size)
                     holder['mm'] = mmap.mmap(fd, size)
                 finally:
                     os.close(fd)
-                return _shm_views(holder['mm'], n_rows, n_pos)
+                return _shm_views(holder['mm'], n_rows, n_pos, n_sel)
 
             pb = prepare_batch(moptions, files, normalizer, alloc)
             meta = {'path': path if 'mm' in holder else None, 'slot': holder.get('slot'), 'n_rows': pb.n_rows, 'n_pos': len(pb.pos),
                     'groups': pb.groups, 'n_windows': pb.n_windows, 'n_reads': pb.n_reads, 'errors': {k: list(v) for k, v in pb.errors.items()},
-                    'contig_len': dict(pb.contig_len), 'timing': dict(pb.timing), 'files': list(pb.files), 'f32': pb.f32}
-            pb.rows = pb.pos = pb.flags = None          # drop the views before a mapping goes away
+                    'contig_len': dict(pb.contig_len), 'timing': dict(pb.timing), 'files': list(pb.files), 'f32': pb.f32,
+                    'n_sel': None if pb.sel is None else len(pb.sel)}
+            pb.rows = pb.pos = pb.flags = pb.sel = None          # drop the views before a mapping goes away
             if 'mm' in holder:
                 holder['mm'].close()
             ready.put(meta)
@@ -779,8 +797,10 @@ def prepared_from_shm(meta, slot_buffer=None) -> Prepared:
         pb.timing[k] += v
     pb.files = meta['files']
     pb.f32 = bool(meta.get('f32', False))
+    n_sel = meta.get('n_sel')
+    views = None
     if meta.get('slot') is not None:
-        pb.rows, pb.pos, pb.flags = _shm_views(slot_buffer(meta['slot']), meta['n_rows'], meta['n_pos'])
+        views = _shm_views(slot_buffer(meta['slot']), meta['n_rows'], meta['n_pos'], n_sel or 0)
     elif meta['path'] is not None:
         fd = os.open(meta['path'], os.O_RDONLY)
         try:
@@ -788,7 +808,11 @@ def prepared_from_shm(meta, slot_buffer=None) -> Prepared:
         finally:
             os.close(fd)
             os.unlink(meta['path'])
-        pb.rows, pb.pos, pb.flags = _shm_views(mm, meta['n_rows'], meta['n_pos'])
+        views = _shm_views(mm, meta['n_rows'], meta['n_pos'], n_sel or 0)
+    if views is not None:
+        pb.rows, pb.pos, pb.flags = views[:3]
+    if n_sel is not None:
+        pb.sel = views[3] if (views is not None and n_sel) else np.zeros(0, np.int32)
     return pb
 
 
@@ -848,36 +872,51 @@ class HipBackend:
                 pb.on_done = None
             return
         R, T = pb.n_rows, len(pb.pos)
-        o_pos, o_flags, end = _shm_layout(R, T)
+        S = 0 if pb.sel is None else len(pb.sel)
+        o_pos, o_flags, end, o_sel = _shm_layout(R, T, S)
         o_cls = -(-end // _ALIGN) * _ALIGN
+        n_cls = R if pb.sel is None else max(S, 1)
         t0 = time.perf_counter()
         i = self._k % self.NSET
         self._k += 1
         self.model.wait_mark(i)                    # the launches that read this set (batch k - NSET) are done
         t1 = time.perf_counter()
-        host, dev = self._staging(self._sets[i], o_cls + R)
+        host, dev = self._staging(self._sets[i], o_cls + n_cls)
         np.copyto(host.view(np.float32, R * 7).reshape(R, 7), pb.rows, casting='same_kind')
         np.copyto(host.view(np.int64, T, o_pos), pb.pos, casting='same_kind')
         np.copyto(host.view(np.uint8, T, o_flags), pb.flags, casting='same_kind')
+        if S:
+            np.copyto(host.view(np.int32, S, o_sel), pb.sel, casting='same_kind')
         if pb.on_done is not None:                 # e.g. the feeder's shared-memory slot goes back to its queue
             pb.on_done()
             pb.on_done = None
         t2 = time.perf_counter()
         self._lib_check(self._lib.dm_model_h2d_async(self.model._h, dev.ptr, host.ptr, end))
-        d_rows, d_pos, d_flags, d_cls = dev.ptr, dev.ptr + o_pos, dev.ptr + o_flags, dev.ptr + o_cls
-        # window centred on row r -> cls[r]; rows 0..9 and R-10..R-1 are padding of the first / last read
+        d_rows, d_pos, d_flags, d_cls, d_sel = dev.ptr, dev.ptr + o_pos, dev.ptr + o_flags, dev.ptr + o_cls, dev.ptr + o_sel
+        if pb.sel is None:
+            # classic form: window centred on row r -> cls[r]; rows 0..9 and R-10..R-1 are padding of the first / last read
+            classify = lambda: self.model.predict_rows_device(d_rows, R, HALF, R - 2 * HALF, d_cls + HALF)
+        else:
+            # compact form: only the windows centred on a base of interest, cls[i] belongs to window sel[i]
+            classify = lambda: (self.model.predict_rows_at_device(d_rows, R, d_sel, S, d_cls) if S else None)
         if pb.f32 and self._precision != self._lib_mod.DM_PREC_F32:      # launches are queued in order: the switch covers this batch only
             self.model.set_option(self._lib_mod.DM_OPT_PRECISION, self._lib_mod.DM_PREC_F32)
-            self.model.predict_rows_device(d_rows, R, HALF, R - 2 * HALF, d_cls + HALF)
+            classify()
             self.model.set_option(self._lib_mod.DM_OPT_PRECISION, self._precision)
             self.timing['f32_batches'] += 1
         else:
-            self.model.predict_rows_device(d_rows, R, HALF, R - 2 * HALF, d_cls + HALF)
-        for (c, s, lo, hi, xlo, xhi) in pb.groups:
+            classify()
+        self.timing['classified'] += (R - 2 * HALF) if pb.sel is None else S
+        xbase = R if pb.sel is None else S
+        for g in pb.groups:
+            c, s, lo, hi, xlo, xhi = g[:6]
             summ = summaries(c, s, pb.contig_len.get(c, 0))
-            summ.add_classified_device(d_pos + 8 * lo, d_flags + lo, d_cls + lo, hi - lo)
+            if pb.sel is None:
+                summ.add_classified_device(d_pos + 8 * lo, d_flags + lo, d_cls + lo, hi - lo)
+            elif g[7] > g[6]:
+                summ.add_classified_device(d_pos + 8 * g[6], d_flags + g[6], d_cls + g[6], g[7] - g[6])
             if xhi > xlo:
-                summ.add_device(d_pos + 8 * (R + xlo), d_flags + R + xlo, xhi - xlo)
+                summ.add_device(d_pos + 8 * (xbase + xlo), d_flags + xbase + xlo, xhi - xlo)
         self.model.mark(i)
         t3 = time.perf_counter()
         self.timing['wait_device'] += t1 - t0

@@ -128,6 +128,16 @@ int dm_predict_windows(dm_model* m, const float* x, int64_t n, float* prob, uint
 int dm_predict_read(dm_model* m, const float* rows, int64_t m_rows, int64_t first, int64_t count,
                     float* prob, uint8_t* cls);
 
+/*
+ * Classify `count` windows of the feature-row matrix picked by their CENTRE rows: window i = rows[centre[i]-10 .. centre[i]+10]
+ * (10 <= centre[i] < m_rows - 10; checked for host arrays only).  The streaming worker classifies only the windows centred on
+ * a base of interest: sum_handler tests refbase == Base before it looks at mod_pred (myDetect.py:1091-1100), so the class of
+ * every other window never reaches the BED - on E. coli 5mC that is 3 of 4 windows.  The reference
+ * computes them because it stores per-read tables; `--storePred 1` (dm_predict_read) still does.  prob / cls: [count].
+ */
+int dm_predict_read_at(dm_model* m, const float* rows, int64_t m_rows, const int32_t* centre, int64_t count, float* prob,
+                       uint8_t* cls);
+
 /* block until all work queued on the model's stream has finished; reports a pending DM_ERANGE of asynchronous launches */
 int dm_model_sync(dm_model* m);
 
@@ -336,9 +346,11 @@ int dm_rows_add_raw(dm_rowsbatch* h, int64_t n_reads, const int32_t* flag, const
                     const int64_t* mev_off, const float* m_mean, const float* m_stdv, const uint64_t* m_length, const char* m_base,
                     const float* s_mean, const float* s_stdv, const int64_t* first_empty, int32_t n_region,
                     const int32_t* region_contig, const int64_t* region_lo, const int64_t* region_hi);
-int64_t dm_rows_info(dm_rowsbatch* h, int64_t* n_rows, int64_t* n_pos, int64_t* read_info, int64_t* mism, int64_t cap_mism, int64_t* n_mism);
-int64_t dm_rows_emit(dm_rowsbatch* h, const int32_t* contig_rank, float* rows, int64_t* pos, uint8_t* flags, int64_t* groups,
-                     int64_t cap_groups, int64_t* contig_len, int64_t n_contig_len, int32_t* in_range);
+int64_t dm_rows_info(dm_rowsbatch* h, int64_t* n_rows, int64_t* n_pos, int64_t* n_sel, int64_t* read_info, int64_t* mism, int64_t cap_mism,
+                     int64_t* n_mism);
+#define DM_ROWS_GROUP 8           /* int64 per group: contig, strand, row_lo, row_hi, xlo, xhi, sel_lo, sel_hi */
+int64_t dm_rows_emit(dm_rowsbatch* h, const int32_t* contig_rank, float* rows, int32_t* sel_row, int64_t* pos, uint8_t* flags,
+                     int64_t* groups, int64_t cap_groups, int64_t* contig_len, int64_t n_contig_len, int32_t* in_range);
 
 #ifdef __cplusplus
 }

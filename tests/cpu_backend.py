@@ -67,6 +67,18 @@ class OracleBackend:
         R = pb.n_rows
         from numpy.lib.stride_tricks import sliding_window_view
         win = sliding_window_view(pb.rows, (21, 7))[:, 0]                  # window centred on row r + 10
+        if getattr(pb, 'sel', None) is not None:
+            # compact form (stream.Prepared.sel): only the windows centred on a base of interest are classified
+            S = len(pb.sel)
+            cls = oracle_np.predict_windows_c(self.w, np.ascontiguousarray(win[pb.sel - 10]))[1].astype(np.uint8) if S else np.zeros(0, np.uint8)
+            for g in pb.groups:
+                c, s, lo, hi, xlo, xhi, slo, shi = g
+                summ = summaries(c, s, pb.contig_len.get(c, 0))
+                if shi > slo:
+                    summ.add(pb.pos[slo:shi], ((pb.flags[slo:shi] & 3) | (cls[slo:shi] << 2)).astype(np.uint8))
+                if xhi > xlo:
+                    summ.add(pb.pos[S + xlo:S + xhi], pb.flags[S + xlo:S + xhi])
+            return
         cls = np.zeros(R, np.uint8)
         cls[10:R - 10] = oracle_np.predict_windows_c(self.w, np.ascontiguousarray(win))[1]
         for (c, s, lo, hi, xlo, xhi) in pb.groups:

@@ -41,9 +41,9 @@ def _detect(wrk, modfile, out, fileid, base, extra=()):
 
 
 def test_base_A_6mA_model_directory_end_to_end(tmp_path, gpu_device):
-    modfile, w = _model_dir(tmp_path, 'rnn_conmodA_E1m2wd21_f7ne1u0_4', 'mod_train_conmodA_E1m2wd21_f3ne1u0', seed=9, scale=4.0)
+    modfile, w = _model_dir(tmp_path, 'rnn_conmodA_E1m2wd21_f7ne1u0_4', 'mod_train_conmodA_E1m2wd21_f3ne1u0', seed=26, scale=4.0)
     wrk = tmp_path / 'reads'
-    files = synth_reads.write_synthetic_run(str(wrk), n_reads=30, reads_per_file=5, genome_len=25000, seed=11, chrom='chr6mA',
+    files = synth_reads.write_synthetic_run(str(wrk), n_reads=30, reads_per_file=5, genome_len=25000, seed=13, chrom='chr6mA',       # min |p1 - 0.5| = 2.0e-4 on this read set
                                             min_len=400, max_len=1600)
     want, margin, nwin = oracle_beds(files, w, 'A')
     assert margin > 1e-4, 'near-tie window in the synthetic set (%.2e): pick another seed' % margin

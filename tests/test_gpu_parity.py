@@ -287,6 +287,32 @@ def test_session_adapter_matches_reference_call_forms(models, tmp_path, gpu_devi
     sess.close()
 
 
+def test_windows_picked_by_centre_row_equal_the_contiguous_call(models, gpu_device):
+    """dm_predict_read_at (the streaming worker's call: only the windows centred on a base of interest) gives, for the picked
+    centres, bit for bit what dm_predict_read gives for all rows - host arrays and device arrays, ragged counts."""
+    w, m = models(26, 4.0)
+    rng = np.random.default_rng(8)
+    rows = np.concatenate([np.zeros((100, 7), np.float32), synth.synthetic_windows(400, seed=3).reshape(-1, 7)[:3000], np.zeros((100, 7), np.float32)])
+    M = len(rows)
+    prob_all, cls_all = m.predict_read(rows, 10, M - 20)
+    for count in (1, 127, 128, 129, 777):
+        centres = np.sort(rng.choice(np.arange(10, M - 10), count, replace=False)).astype(np.int32)
+        prob, cls = m.predict_read_at(rows, centres)
+        assert np.array_equal(prob.view(np.uint32), prob_all[centres - 10].view(np.uint32)) and np.array_equal(cls, cls_all[centres - 10])
+    d_rows = model.DeviceArray.from_host(rows, gpu_device)
+    centres = np.arange(10, M - 10, 4, dtype=np.int32)
+    d_c = model.DeviceArray.from_host(centres, gpu_device)
+    d_cls = model.DeviceArray((len(centres),), np.uint8, gpu_device)
+    m.predict_read_at(d_rows, d_c, cls=d_cls, want_prob=False)
+    m.sync()
+    assert np.array_equal(d_cls.to_host(), cls_all[centres - 10])
+    from deepmod_amd import _lib
+    with pytest.raises(_lib.DeepModHipError):
+        m.predict_read_at(rows, np.array([5], np.int32))            # centre - 10 < 0
+    for d in (d_rows, d_c, d_cls):
+        d.free()
+
+
 def test_layer_major_experiment_kernel_is_refused_or_agrees(gpu_device):
     """DM_PREC_F16X3_LM (tools/experiments/f16lm) is not part of the product build: the library refuses it unless it was
     built with -DDM_WITH_F16X3_LM, in which case it has to pass the same parity check as the product kernels."""

@@ -196,6 +196,23 @@ def _same_batch(a, b):
     assert norm(a.errors) == norm(b.errors), (dict(a.errors), dict(b.errors))
 
 
+def _compact_form_is_the_classic_form_without_the_other_bases(c, classic):
+    """dm_rows_emit's compact form: the same feature rows; sel = the rows that are centres of windows on a base of interest (flag
+    bit 0), their positions and flags, then the same extras - rows of other bases appear nowhere (the summary ignores them)."""
+    R = classic.n_rows
+    assert c.sel is not None and classic.sel is None and c.n_rows == R and np.array_equal(c.rows, classic.rows)
+    want = np.flatnonzero((classic.flags[:R] & 1) != 0)
+    assert np.array_equal(c.sel, want) and len(want) < 0.5 * R
+    S = len(want)
+    assert np.array_equal(c.pos[:S], classic.pos[want]) and (c.flags[:S] == 3).all() and (classic.flags[want] == 3).all()
+    assert np.array_equal(c.pos[S:], classic.pos[R:]) and np.array_equal(c.flags[S:], classic.flags[R:])
+    assert len(c.groups) == len(classic.groups)
+    for g, h in zip(c.groups, classic.groups):
+        assert g[:6] == h[:6]
+        assert np.array_equal(c.sel[g[6]:g[7]], want[(want >= g[2]) & (want < g[3])])
+    assert c.n_windows == classic.n_windows and c.n_reads == classic.n_reads and c.contig_len == classic.contig_len
+
+
 def test_compiled_batch_equals_python_batch_on_feature_and_packed_containers(tmp_path):
     """dm_rows_add_packed + dm_rows_info + dm_rows_emit against the per-read numpy path (stream._prepare_batch_py): feature
     containers of both formats, two contigs, both strands, a read too short to be called, deletions (extra rows)."""
@@ -214,10 +231,11 @@ def test_compiled_batch_equals_python_batch_on_feature_and_packed_containers(tmp
                                             min_len=30, max_len=40)
     files = a + packed + short
     for base in 'CA':
-        mo = {'Base': base, 'outFolder': str(tmp_path), 'fnum': 7, 'hidden': 100, 'windowsize': 21}
+        mo = {'Base': base, 'outFolder': str(tmp_path), 'fnum': 7, 'hidden': 100, 'windowsize': 21, 'select_base': False}
         got = stream._prepare_batch_c(mo, files)
         ref = stream._prepare_batch_py(mo, files)
         _same_batch(got, ref)
+        _compact_form_is_the_classic_form_without_the_other_bases(stream._prepare_batch_c(dict(mo, select_base=True), files), got)
         assert got.n_reads == 15 and len(got.errors['Less Event']) == 2 and len(got.groups) >= 3
         assert (got.flags[got.n_rows:] & 1).all() and len(got.pos) > got.n_rows        # extras exist and are all of the wanted base
 
@@ -230,9 +248,11 @@ def test_compiled_batch_equals_python_batch_on_raw_containers(tmp_path):
     mo = {'Base': 'C', 'outFolder': str(tmp_path), 'fnum': 7, 'hidden': 100, 'windowsize': 21, 'Ref': fasta, 'alignStr': 'minimap2',
           'region': [[None, None, None]], 'ConUnk': True, 'SignalGroup': 'simple', 'outLevel': 3}
     norm = _OracleNormalizer()
+    mo['select_base'] = False
     got = stream._prepare_batch_c(dict(mo), files, lambda: norm)
     ref = stream._prepare_batch_py(dict(mo), files, lambda: norm)
     _same_batch(got, ref)
+    _compact_form_is_the_classic_form_without_the_other_bases(stream._prepare_batch_c(dict(mo, select_base=True), files, lambda: norm), got)
     assert got.n_reads >= 12 and got.n_windows > 5000 and got.rows[:, :4].sum() > 0 and got.rows[:, 4:].any()
     # a region filter that keeps the first half of the contig only, and a region on another contig (nothing passes)
     for region, expect_some in (([['chrS', None, 15000]], True), ([['chrT', None, None]], False)):

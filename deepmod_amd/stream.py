@@ -1149,6 +1149,8 @@ class StreamEngine:
         everyone = gather({"keys": mine, "len": lens}) if self.world > 1 else [{"keys": mine, "len": lens}]
         keys = sorted(set(k for e in everyone for k in e["keys"]))
         beds, parts = {}, {}
+        # (moptions['force_scatter_merge']: the scatter form on a single rank too - how the GPU tests run this code path on one GPU)
+        scattered = scatter_fn is not None and (self.world > 1 or bool(self.mo.get('force_scatter_merge')))
         out_path = lambda chrom, strand: '%s/mod_pos.%s%s.%s.bed' % (self.mo['outFolder'], chrom, strand, self.mo['Base'])
         for key in keys:
             chrom, strand = key.split("\t")
@@ -1157,7 +1159,7 @@ class StreamEngine:
             if s is None:                               # this rank saw no read of that contig x strand: zeros
                 s = self.summaries[(chrom, strand)] = self.backend.new_summary(length)
             s.grow(length)                              # exactly the common length (no growth slack): equal counts on every rank
-            if self.world > 1 and scatter_fn is not None:
+            if scattered:
                 s.sync()                                # every rank: positions this rank dropped as out of range fail the run here
                 first, count = scatter_fn(s)
                 touch, cov, mod = s.fetch_slice()
@@ -1182,9 +1184,9 @@ class StreamEngine:
                             fh.write(bed)
             s.close()
         self.summaries = {}
-        if self.world > 1 and scatter_fn is not None and write:
+        if scattered and write:
             # every rank's parts are on disk once its sizes have been gathered; rank 0 joins them
-            sizes = gather({"parts": parts})
+            sizes = gather({"parts": parts}) if self.world > 1 else [{"parts": parts}]
             if self.rank == 0:
                 for key in keys:
                     chrom, strand = key.split("\t")

@@ -132,15 +132,15 @@ class Graph:
 
 
 def issued_units(schedule):
-    """average issued MFMA units per k-slot of the whole graph (x3 everywhere = 3.0), weighted with the k16-steps of the
-    product kernel's tiles; step 0 counts only the k16-steps that are not skipped (zero state)."""
+    """issued MFMA units per k-slot of the whole graph, weighted with the k16-steps of the product kernel's tiles; the zero-state
+    k16-steps of step 0 are not issued at all (x3 everywhere = 3 * 345 / 363; times the K 208/201 and N 104/100 padding that is the
+    kernel's 3.09 issued per algorithmic unit)."""
     sched = schedule if callable(schedule) else (lambda s, l: schedule)
     tot = iss = 0.0
     for s in range(LIVE):
         for l in range(3):
-            ks = KSTEPS[l] - (6 if s == 0 else 0)
-            tot += ks
-            iss += ks * UNITS[sched(s, l)]
+            tot += KSTEPS[l]
+            iss += (KSTEPS[l] - (6 if s == 0 else 0)) * UNITS[sched(s, l)]
     return iss / tot
 
 

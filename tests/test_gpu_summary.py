@@ -113,6 +113,38 @@ def test_reduce_scatter_single_rank_and_sliced_bed(gpu_device, tmp_path):
     c.close()
 
 
+def test_streaming_finalize_through_the_scatter_merge_on_one_rank(gpu_device, tmp_path):
+    """StreamEngine.finalize's multi-rank form (dm_summary_reduce_scatter on a real communicator, dm_summary_fetch_slice, the slice
+    formatter, part files joined by rank 0) forced onto one rank: the BED files equal those of the single-rank form."""
+    import os
+    from deepmod_amd import comm, stream, synth, synth_reads
+    files = synth_reads.write_synthetic_run(str(tmp_path / 'in'), n_reads=12, reads_per_file=3, genome_len=8000, seed=3, chrom='chrA',
+                                            min_len=200, max_len=600)
+    prefix = str(tmp_path / 'model' / 'm')
+    os.makedirs(os.path.dirname(prefix))
+    synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)
+    beds = {}
+    for tag in ('plain', 'scatter'):
+        out = str(tmp_path / ('out_' + tag))
+        os.makedirs(out)
+        mo = {'fnum': 7, 'hidden': 100, 'windowsize': 21, 'modfile': [prefix, os.path.dirname(prefix) + '/'], 'outFolder': out, 'Base': 'C',
+              'force_scatter_merge': tag == 'scatter'}
+        backend = stream.HipBackend(mo, gpu_device)
+        eng = stream.StreamEngine(mo, backend)
+        eng.run(iter([files[:2], files[2:]]), feeders=1)
+        if tag == 'plain':
+            eng.finalize(None, None)
+        else:
+            c = comm.Communicator.from_rendezvous(gpu_device, comm.FileRendezvous(str(tmp_path / 'rdv'), 0, 1))
+            eng.finalize(None, lambda s: s.reduce_scatter(c))
+            assert c.stats()["collectives"] == 2                  # one per contig x strand
+            c.close()
+        backend.close()
+        beds[tag] = {f: open(os.path.join(out, f), 'rb').read() for f in sorted(os.listdir(out))}
+    assert sorted(beds['plain']) == ['mod_pos.chrA+.C.bed', 'mod_pos.chrA-.C.bed'] and beds['scatter'] == beds['plain']
+    assert all(len(b) > 500 for b in beds['plain'].values())
+
+
 def test_summary_grow_keeps_counts(gpu_device):
     s = summary.PositionSummary(1000, gpu_device)
     pos, flags = _random_bases(20000, 1000, seed=4)

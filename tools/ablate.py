@@ -33,8 +33,7 @@ VARIANTS = {
     "s_floor": ["-DDM16S_ABL_NOCELL", "-DDM16S_ABL_NODMA", "-DDM16S_ABL_NOBAR", "-DDM16S_ABL_NOLDSA"],
     "s_ad2": ["-DDM16S_ADIST=2"], "s_ad4": ["-DDM16S_ADIST=4"], "s_ad5": ["-DDM16S_ADIST=5"], "s_ad6": ["-DDM16S_ADIST=6"], "s_pre0": ["-DDM16S_PRE=0"], "s_pre1": ["-DDM16S_PRE=1"], "s_pre3": ["-DDM16S_PRE=3"], "s_pre4": ["-DDM16S_PRE=4"],
     "s_nocell_noldsa": ["-DDM16S_ABL_NOCELL", "-DDM16S_ABL_NOLDSA"],
-    # round 3: cross terms as one int8 MFMA (timing only): with / without the extra VALU work such a stage carries
-    "s_i8t": ["-DDM16S_ABL_I8T"], "s_i8t_nox": ["-DDM16S_ABL_I8T", "-DDM16S_ABL_I8T_NOX"],
+    # (round 3's timing-only "int8 cross terms" variants s_i8t / s_i8t_nox became the real DM_PREC_F16I8: git show 8a84c8d:deepmod_amd/csrc/lstm_f16s.hip.inc)
     "trace": ["-DDM_TRACE"],                                   # f16x3 kernel: per-wave timeline of one stage
     "w4": ["-DDM16_WAVES=4", "-DDM16_MT=2"],                   # f16x3 kernel: 4 waves x 2 M-tiles (one wave per SIMD)
     "w4timing": ["-DDM16_WAVES=4", "-DDM16_MT=2", "-DDM_TIMING"],

@@ -80,10 +80,12 @@ extern "C" {
                               -DDM_WITH_F16X3_LM (DM_INFO_HAS_F16X3_LM), otherwise refused with DM_EINVAL. */
 #define DM_PREC_F16I8 3    /* OPT-IN: the step-major kernel with hi*hi in f16 and BOTH cross terms of every product as one int8 MFMA
                               (v_mfma_i32_32x32x32_i8, int32 accumulation, folded into the fp32 pre-activations per tile): 2 issued
-                              matrix units per product instead of 3, ~19 % less time per window.  Operands carry ~19 bits instead
-                              of 22: max |dp| vs the fp32 graph 3-5e-5 at weight scale 4 (DM_PREC_F16X3: 3e-6; tolerance of the
-                              path: 1e-4), classes equal away from near ties.  Same range contract as DM_PREC_F16X3 (the raw
-                              features never ride the int8 product).  Never selected by default. */
+                              matrix units per product instead of 3, 10-12 % less time per window.  Operands carry ~19 bits instead
+                              of 22.  REDUCED PRECISION: on 10^6 windows at weight scale 4 the worst window is 1.1e-4 from the fp32
+                              graph, 2 windows exceed the path's 1e-4 tolerance and 99.99 % are below 6.5e-5 (DM_PREC_F16X3: worst
+                              9e-6); at weight scale 1: 6e-6.  Documented bound 2e-4; classes equal wherever p1 is further than that
+                              from 0.5.  Same range contract as DM_PREC_F16X3 (the raw features never ride the int8 product).
+                              Never selected by default. */
 /* dm_model_get_info keys */
 #define DM_INFO_PRECISION 1          /* DM_PREC_* in effect */
 #define DM_INFO_F16_REPRESENTABLE 2  /* 1 if the weights fit DM_PREC_F16X3 */

@@ -88,3 +88,31 @@ def test_summary_of_a_million_bases(full_run, gpu_device):
     assert np.array_equal(c1, np.bincount(pos[covd], minlength=length).astype(np.int32))
     assert np.array_equal(m1, np.bincount(pos[covd & (cls == 1)], minlength=length).astype(np.int32))
     assert np.array_equal(t1, t16) and np.array_equal(c1, c16) and np.array_equal(m1, m16)
+
+
+def test_opt_in_int8_precision_on_the_million_windows(full_run):
+    """DM_PREC_F16I8 at full size, against the default kernel on all 10^6 windows.  The tail is what the small parity tests cannot
+    see (profiles/r03/i8_tail.txt: worst window 1.1e-4 from the oracle, 2 of 10^6 above 1e-4, 99.99 % below 6.5e-5; the default:
+    9e-6): the assertions are its documented bound - NOT the path's 1e-4 - plus classes equal wherever the default is not within that
+    bound of a tie, bit-identical reruns and permutation / split invariance."""
+    _, m, x, prob, cls = full_run
+    m.set_precision("f16i8")
+    try:
+        p8 = np.empty((N, 2), np.float32)
+        c8 = np.empty(N, np.uint8)
+        for off in range(0, N, BATCH):
+            p, c = m.predict_windows(x[off:off + BATCH])
+            p8[off:off + BATCH] = p
+            c8[off:off + BATCH] = c
+        d = np.abs(p8 - prob).max(axis=1)
+        assert d.max() <= 2e-4, float(d.max())
+        assert np.quantile(d, 0.9999) <= 1e-4 and int((d > 1e-4).sum()) <= 20, (float(np.quantile(d, 0.9999)), int((d > 1e-4).sum()))
+        clear = np.abs(prob[:, 1] - 0.5) > 2e-4
+        assert np.array_equal(c8[clear], cls[clear])
+        idx = np.random.default_rng(9).permutation(N)[:100_000]
+        p, c = m.predict_windows(x[idx])
+        assert np.array_equal(p, p8[idx]) and np.array_equal(c, c8[idx])
+        print("f16i8 vs f16x3 on %d windows: max |dp| %.3g, p99.99 %.3g, %d windows above 1e-4, %d classes differ (all within 2e-4 of a tie)"
+              % (N, float(d.max()), float(np.quantile(d, 0.9999)), int((d > 1e-4).sum()), int((c8 != cls).sum())))
+    finally:
+        m.set_precision("f16x3")

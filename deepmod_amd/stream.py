@@ -344,7 +344,7 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                     keep.extend([flag, pos1, rlen, cidx, ev_read, skip, cig_b, seq_b, ref_ptr, ref_len, cig_ptr, seq_ptr, mev_off, m_mean, m_stdv,
                                  m_len, m_base, s_mean, s_stdv, first_empty, rg_c, rg_lo, rg_hi])
                     _lib.check(lib.dm_rows_add_raw(h, nrec, flag.ctypes.data, pos1.ctypes.data, cig_ptr, seq_ptr, rlen.ctypes.data, cidx.ctypes.data,
-                                                   ev_read.ctypes.data, skip.ctypes.data, nct, ref_ptr, ref_len.ctypes.data, mev_off.ctypes.data,
+                                                   ev_read.ctypes.data, skip.ctypes.data, nct, ref_ptr, ref_len.ctypes.data, len(mev_off) - 1, mev_off.ctypes.data,
                                                    m_mean.ctypes.data, m_stdv.ctypes.data, m_len.ctypes.data, m_base.ctypes.data, s_mean.ctypes.data,
                                                    s_stdv.ctypes.data, first_empty.ctypes.data, len(region), rg_c.ctypes.data, rg_lo.ctypes.data,
                                                    rg_hi.ctypes.data))

@@ -345,7 +345,7 @@ int dm_rows_add_packed(dm_rowsbatch* h, int64_t n_reads, const int64_t* row_off,
 int dm_rows_add_raw(dm_rowsbatch* h, int64_t n_reads, const int32_t* flag, const int64_t* pos1, const char* const* cigar,
                     const char* const* readseq, const int64_t* readseq_len, const int32_t* contig, const int32_t* ev_read,
                     const uint8_t* skip, int32_t n_contigs, const char* const* refseq, const int64_t* refseq_len,
-                    const int64_t* mev_off, const float* m_mean, const float* m_stdv, const uint64_t* m_length, const char* m_base,
+                    int64_t n_event_reads, const int64_t* mev_off, const float* m_mean, const float* m_stdv, const uint64_t* m_length, const char* m_base,
                     const float* s_mean, const float* s_stdv, const int64_t* first_empty, int32_t n_region,
                     const int32_t* region_contig, const int64_t* region_lo, const int64_t* region_hi);
 int64_t dm_rows_info(dm_rowsbatch* h, int64_t* n_rows, int64_t* n_pos, int64_t* n_sel, int64_t* read_info, int64_t* mism, int64_t cap_mism,

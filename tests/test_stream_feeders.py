@@ -260,3 +260,33 @@ def test_compiled_batch_equals_python_batch_on_raw_containers(tmp_path):
         r2 = stream._prepare_batch_py(dict(mo, region=region), files, lambda: norm)
         _same_batch(g2, r2)
         assert (g2.n_reads > 0) == expect_some and g2.n_reads < got.n_reads
+
+
+def test_compact_batch_without_any_base_of_interest(tmp_path):
+    """A batch whose reads hold no base of interest at all (an all-T genome, --Base C): feature rows but no window to classify, no
+    positions, no extras - through the compiled path, the shared-memory hand-over and the engine (no BED file is written)."""
+    from deepmod_amd import predstore
+    files = synth_reads.write_synthetic_run(str(tmp_path / 'in'), n_reads=4, reads_per_file=2, genome_len=4000, seed=3, chrom='chrA',
+                                            min_len=120, max_len=300)
+    for f in files:                                   # rewrite the tables: every reference base a 'T'
+        reads = predstore.load_feature_container(f)
+        for rd in reads:
+            bmi = rd['base_map_info']
+            bmi['refbase'] = np.where(bmi['refbase'] == '-', '-', 'T')
+        predstore.save_feature_container(f, reads)
+    mo = {'Base': 'C', 'outFolder': str(tmp_path / 'out'), 'fnum': 7, 'hidden': 100, 'windowsize': 21}
+    os.makedirs(mo['outFolder'])
+    pb = stream._prepare_batch_c(mo, files)
+    assert pb.n_rows > 0 and pb.sel is not None and len(pb.sel) == 0 and len(pb.pos) == 0 and pb.n_reads == 4
+    work, ready = queue.Queue(), queue.Queue()
+    work.put((files, 0, 0))
+    shm = str(tmp_path / 'shm')
+    os.makedirs(shm)
+    stream.feeder_process_main(mo, work, ready, 0, shm, 0)
+    meta = ready.get()
+    got = stream.prepared_from_shm(meta)
+    assert got.n_rows == pb.n_rows and got.sel is not None and len(got.sel) == 0 and np.array_equal(got.rows, pb.rows)
+    eng = stream.StreamEngine(mo, OracleBackend(synth.synthetic_weights(26, 4.0)))
+    eng.consume(got)
+    beds = eng.finalize(None, None)
+    assert all(len(b) == 0 for b in beds.values()) and not [f for f in os.listdir(mo['outFolder']) if f.endswith('.bed')]

@@ -91,6 +91,7 @@ SIGNATURES = [
     ("dm_rows_add_packed", _c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("dm_rows_add_raw", _c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _c.c_int32, _vp, _vp, _vp]),
+    ("dm_rows_add_mapped", _c.c_int, [_vp, _i64] + [_vp] * 16),
     ("dm_rows_info", _i64, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64), _vp, _vp, _i64, _c.POINTER(_i64)]),
     ("dm_rows_emit", _i64, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32)]),
 ]

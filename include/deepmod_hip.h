@@ -348,6 +348,11 @@ int dm_rows_add_raw(dm_rowsbatch* h, int64_t n_reads, const int32_t* flag, const
                     int64_t n_event_reads, const int64_t* mev_off, const float* m_mean, const float* m_stdv, const uint64_t* m_length, const char* m_base,
                     const float* s_mean, const float* s_stdv, const int64_t* first_empty, int32_t n_region,
                     const int32_t* region_contig, const int64_t* region_lo, const int64_t* region_hi);
+/* reads whose alignment table the caller already has (get_Feature's rows are built from the event tables at emit time) */
+int dm_rows_add_mapped(dm_rowsbatch* h, int64_t n_reads, const int64_t* bmi_off, const char* refbase, const char* readbase,
+                       const int64_t* refbasei, const int64_t* start_clip, const int64_t* end_clip, const int32_t* contig,
+                       const int32_t* strand, const int64_t* mev_off, const float* m_mean, const float* m_stdv, const uint64_t* m_length,
+                       const char* m_base, const float* s_mean, const float* s_stdv, const int64_t* first_empty);
 int64_t dm_rows_info(dm_rowsbatch* h, int64_t* n_rows, int64_t* n_pos, int64_t* n_sel, int64_t* read_info, int64_t* mism, int64_t cap_mism,
                      int64_t* n_mism);
 #define DM_ROWS_GROUP 8           /* int64 per group: contig, strand, row_lo, row_hi, xlo, xhi, sel_lo, sel_hi */

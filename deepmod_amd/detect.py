@@ -642,8 +642,14 @@ def mDetect_manager(moptions):
         print('Total files=%d' % len(files))
         out_root = moptions['outFolder'] + moptions['FileID']
         os.makedirs(out_root, exist_ok=True)
-        items = plan_batches(files, moptions['files_per_thread'])
         streamed = not moptions.get('storePred', 0)
+        per_batch = moptions['files_per_thread']
+        if streamed:
+            # a streaming run writes nothing per batch: the batch is only the unit the feeders take from the work queue, and the
+            # counters are sums, so the BED does not depend on it. The reference's default (1000 single-read FAST5 files) would put
+            # a whole run of multi-read containers into ONE batch and leave all feeders but one idle: keep >= 8 batches per feeder
+            per_batch = max(1, min(per_batch, -(-len(files) // (8 * moptions['threads']))))
+        items = plan_batches(files, per_batch)
         if streamed:
             _BASE_OF_RUN[0] = moptions['Base']
             ledger, stats = _run_streaming_detect(moptions, ctx, pmanager, items, ngpu)

@@ -600,6 +600,12 @@ def _print_stream_stats(stats, wall):
           % (tot['submit_wait_device'] / len(stats), tot['submit_stage'] / len(stats), tot['submit_launch'] / len(stats))
           + ('; signal server %.1f s (%.1f s inside dm_signal_event_stats_batch) for %d requests'
              % (tot['signal_server'] / len(stats), tot['signal_server_call'] / len(stats), tot['signal_requests']) if tot['signal_requests'] else ''))
+    if 'at_rank_start' in tot and 'at_drained' in tot:
+        n, r0 = len(stats), tot['at_rank_start'] / len(stats)
+        print('\ttimeline, seconds after the command began its detect step (mean over ranks): GPU process running %.2f, model on the device %.2f, '
+              'first batch from a feeder %.2f, last batch %.2f, device drained %.2f, BED written and process done %.2f'
+              % (r0, r0 + tot['at_backend_ready'] / n, r0 + tot['at_first_batch'] / n, r0 + tot['at_last_batch'] / n, r0 + tot['at_drained'] / n,
+                 tot['at_rank_end'] / n))
 
 
 def _run_summary_jobs(moptions, ctx, pmanager, ngpu):
@@ -627,6 +633,7 @@ def mDetect_manager(moptions):
         # the reference marks this branch of sum_handler "should not used now" (myDetect.py:1054-1087); neither run mode builds it,
         # and writing plain mod_pos.* files for a run that asked for cluster_mod_pos.* would be a silent change of meaning
         raise NotImplementedError("--mod_cluster 1 is not built (the reference marks that branch 'should not used now', myDetect.py:1054)")
+    moptions['_t_manager'] = time.time()
     ctx = multiprocessing.get_context('spawn')      # never fork a process that may hold a HIP context
     pmanager = ctx.Manager()
     ngpu = max(1, int(moptions.get('gpus', 1)))

@@ -1091,6 +1091,7 @@ class StreamEngine:
                 t0 = time.perf_counter()
                 self.backend = make_backend()
                 self.stats['backend_init'] += time.perf_counter() - t0
+            self.stats['at_backend_ready'] = time.perf_counter() - t_start
             done = 0
             while done < n_procs:
                 t0 = time.perf_counter()
@@ -1108,14 +1109,17 @@ class StreamEngine:
                 elif 'failed' in item:
                     raise RuntimeError('a feeder process failed:\n' + item['failed'])
                 else:
+                    self.stats.setdefault('at_first_batch', time.perf_counter() - t_start)
                     pb = prepared_from_shm(item, slot_buffer)
                     if item.get('slot') is not None:
                         pb.on_done = (lambda i=item['slot']: free_slots.put(i))
                         self.stats['slot_batches'] += 1
                     self.consume(pb)
             t0 = time.perf_counter()
+            self.stats['at_last_batch'] = t0 - t_start
             self.backend.sync()
             self.stats['drain'] += time.perf_counter() - t0
+            self.stats['at_drained'] = time.perf_counter() - t_start
             clean = True
         finally:
             for pr in procs:
@@ -1244,6 +1248,8 @@ def _stream_rank_body(moptions, rank, world, device, work, result_q, feeders, fe
     use_procs = feeder_procs > 0 and hasattr(work, 'get')
     backend = None if use_procs else HipBackend(moptions, device)       # with feeder processes: created once they are running
     eng = StreamEngine(moptions, backend, rank, world)
+    if moptions.get('_t_manager'):
+        eng.stats['at_rank_start'] = time.time() - moptions['_t_manager']     # process start-up + imports of this rank
     if moptions.get('Ref') and os.path.isfile(moptions['Ref']):
         from . import readmap
         eng.set_reference_lengths({c: len(s) for c, s in readmap.read_fasta(moptions['Ref']).items()})
@@ -1264,6 +1270,8 @@ def _stream_rank_body(moptions, rank, world, device, work, result_q, feeders, fe
         eng.stats.update({'comm_' + k: v for k, v in communicator.stats().items()})
         communicator.close()
     backend.close()
+    if moptions.get('_t_manager'):
+        eng.stats['at_rank_end'] = time.time() - moptions['_t_manager']
     out = {'rank': rank, 'errors': dict(eng.errors), 'stats': dict(eng.stats)}
     if result_q is not None:
         result_q.put(out)

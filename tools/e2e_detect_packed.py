@@ -38,6 +38,8 @@ if __name__ == "__main__":
     for rep, nf in enumerate([feeders[0]] + feeders):          # the first run also warms the page cache: not reported
         cmd = [sys.executable, os.path.join(ROOT, "bin", "DeepMod.py"), "detect", "--wrkBase", wrk, "--modfile", prefix, "--outFolder",
                "%s/out%d" % (tmp, rep), "--Base", "C", "--gpus", "1", "--threads", str(nf), "--FileID", "s"] + sys.argv[3:]
+        if os.environ.get("DM_E2E_PROF") and rep:                # kernel trace of the rank process(es): where the GPU time goes
+            cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", "%s/f%d" % (os.environ["DM_E2E_PROF"], nf), "--"] + cmd
         t0 = time.time()
         res = subprocess.run(cmd, capture_output=True, text=True)
         wall = time.time() - t0
@@ -47,6 +49,6 @@ if __name__ == "__main__":
         if rep == 0:
             continue
         for ln in res.stdout.splitlines():
-            if "Streaming detect" in ln or "host stages" in ln or "windows run" in ln:
+            if "Streaming detect" in ln or "host stages" in ln or "timeline" in ln:
                 print("   ", ln.strip())
         print("%d feeder processes: whole command %.2f s" % (nf, wall), flush=True)

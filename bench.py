@@ -227,6 +227,33 @@ def extras(m, _lib, model, precision, x_dev0, x_host0, prob_dev, cls_dev, reps=4
     return out
 
 
+class _FileControl:
+    """Barrier / max over the ranks through the rendezvous files: the control plane of a run whose RCCL set-up failed."""
+
+    def __init__(self, rdv):
+        self.rdv, self.round = rdv, 0
+
+    def max(self, value: float) -> float:
+        self.round += 1
+        return max(self.rdv.all_gather_json("control_%d" % self.round, value))
+
+    def barrier(self):
+        self.max(0.0)
+
+
+def _agree(rdv, name, communicator, error):
+    """All ranks keep the communicator, or none does: (communicator, None) or (None, every rank's error)."""
+    errors = [e for e in rdv.all_gather_json(name, error) if e]
+    if not errors:
+        return communicator, None
+    if communicator is not None:
+        try:
+            communicator.close()
+        except Exception:
+            pass
+    return None, "; ".join(errors)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,13 +283,31 @@ def main():
         raise SystemExit("bench.py: no gfx950 device visible; there is no CPU fallback")
     device = local_rank if dist_mode else 0
 
-    communicator = rdv = None
+    communicator = rdv = control = comm_error = None
     if dist_mode:
         # torch.distributed.run is only the launcher: ranks find each other through a file rendezvous keyed by the
         # launcher's pid (the common parent of all ranks) and the master port, and talk RCCL through the product's C ABI
         rdv = dmcomm.FileRendezvous(os.path.join("/tmp", "deepmod_bench_rdv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))),
                                     rank, world, timeout=300.0, fresh_after=time.time() - 600.0)
-        communicator = dmcomm.Communicator.from_rendezvous(device, rdv)
+        # RCCL could never be exercised on more than one rank while this was written (no multi-GPU box was reachable): a failure to
+        # set it up must not cost the run its throughput line - the data path has no collective.  The ranks agree on the outcome;
+        # without RCCL the final merge is skipped, barriers / the max go through the rendezvous files, and the JSON line says so
+        try:
+            if os.environ.get("DM_BENCH_BREAK_RCCL") == "1":      # test hook: the degraded mode below, without a broken RCCL
+                raise RuntimeError("DM_BENCH_BREAK_RCCL=1")
+            uid = dmcomm.rccl_unique_id() if rank == 0 else None
+        except Exception as exc:
+            uid, comm_error = b"", "dm_rccl_unique_id: %r" % (exc,)
+        uid = rdv.broadcast("rccl_id", uid)
+        if uid:
+            try:
+                communicator = dmcomm.Communicator(device, uid, rank, world)
+            except Exception as exc:
+                comm_error = "dm_comm_create on rank %d: %r" % (rank, exc)
+        elif comm_error is None:
+            comm_error = "rank 0 could not create the RCCL id"
+        communicator, comm_error = _agree(rdv, "comm_up", communicator, comm_error)
+        control = communicator if communicator is not None else _FileControl(rdv)
 
     weights = synth.synthetic_weights(seed=26, scale=4.0)     # ~50 % of the windows are class 1: both summary branches are taken
     m = model.BiLSTMModel(weights, device=device, precision=args.precision)
@@ -322,15 +367,20 @@ def main():
         step(i)
     if communicator is not None:
         # untimed, part of the warm-up: the first reduce of this size makes RCCL set up its channels and buffers
-        warm = summary.PositionSummary(CONTIG_LEN, device=device)
-        warm.follow(m)
-        warm.reduce_scatter(communicator)
-        warm.sync()
-        warm.close()
+        try:
+            warm = summary.PositionSummary(CONTIG_LEN, device=device)
+            warm.follow(m)
+            warm.reduce_scatter(communicator)
+            warm.sync()
+            warm.close()
+        except Exception as exc:
+            comm_error = "first ncclReduceScatter on rank %d: %r" % (rank, exc)
+        communicator, comm_error = _agree(rdv, "comm_warm", communicator, comm_error)
+        control = communicator if communicator is not None else _FileControl(rdv)
     sync_all()
     m.profile_reset()
-    if communicator is not None:
-        communicator.barrier()
+    if control is not None:
+        control.barrier()
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -338,11 +388,14 @@ def main():
     if communicator is not None:
         summ.reduce_scatter(communicator)     # the only collective: int32 touch|cov|mod summed over the ranks, one slice per rank (ncclReduceScatter)
     sync_all()
-    if communicator is not None:
-        communicator.barrier()
+    if control is not None:
+        control.barrier()
     elapsed_rank = time.perf_counter() - t0
-    elapsed = communicator.max(elapsed_rank) if communicator is not None else elapsed_rank
+    elapsed = control.max(elapsed_rank) if control is not None else elapsed_rank
     per_rank = None
+    if control is not None and communicator is None:        # no RCCL: every rank reports the totals of its own counters
+        per_rank = rdv.all_gather_json("rate", {"rank": rank, "windows_per_s": BATCH * args.steps / elapsed_rank, "elapsed_s": elapsed_rank,
+                                                "device": device, "slice_sums": [int(a.sum()) for a in summ.fetch()]})
     if communicator is not None:
         sl = summ.fetch_slice()               # this rank's slice of the merged counters
         per_rank = rdv.all_gather_json("rate", {"rank": rank, "windows_per_s": BATCH * args.steps / elapsed_rank,
@@ -356,9 +409,9 @@ def main():
     if rank == 0:
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = (kwindows / max(launches, 1)) * FLOP_PER_WINDOW / avg_launch_s / 1e12
-        if communicator is None:
+        if per_rank is None:
             check = [int(a.sum()) for a in summ.fetch()]
-        else:                                 # the slices of all ranks together are the merged counters
+        else:                                 # the slices of all ranks together are the merged counters (no RCCL: the ranks' own totals)
             check = [sum(r["slice_sums"][k] for r in per_rank) for k in range(3)]
         traffic = measured_traffic(args.precision)
         out = {
@@ -388,6 +441,10 @@ def main():
                                     reduce_bytes_per_rank=12 * CONTIG_LEN, per_rank=per_rank,
                                     measured_on_hardware_with_more_than_one_rank=bool(world > 1),
                                     note="`collectives` / `bytes` count one untimed warm-up merge of the same size and the timed one")
+        elif control is not None:
+            out["multi_gpu"] = {"collective": "NOT RUN: RCCL could not be set up, the final merge of the counters was skipped (barriers and the "
+                                              "max over ranks went through the rendezvous files); the data path has no collective, so `value` stands",
+                                "rccl_error": comm_error, "per_rank": per_rank, "measured_on_hardware_with_more_than_one_rank": bool(world > 1)}
         if world == 1 and not args.no_extras:
             out["extras"] = extras(m, _lib, model, args.precision, x_dev[0], x0, prob_dev, cls_dev)
         if world == 1 and not args.no_cpu_baseline:
@@ -401,8 +458,9 @@ def main():
             pass
         print(json.dumps(out), flush=True)
 
+    if control is not None:
+        control.barrier()
     if communicator is not None:
-        communicator.barrier()
         communicator.close()
 
 

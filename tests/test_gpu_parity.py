@@ -362,6 +362,27 @@ def test_bench_distributed_path_single_rank(gpu_device):
     assert "ncclReduceScatter" in mg["collective"] or "ncclReduce" in mg["collective"]
 
 
+def test_bench_keeps_its_line_when_rccl_cannot_be_set_up(gpu_device):
+    """RCCL never ran on more than one rank here: if it cannot be set up on the scaling box, the ranks agree to skip the final merge,
+    barrier through the rendezvous files and still print the throughput line, with the failure named in it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, DM_BENCH_FORCE_DIST="1", DM_BENCH_BREAK_RCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["value"] > 1e6 and out["summary_check"]["touch"] > 0
+    mg = out["multi_gpu"]
+    assert mg["collective"].startswith("NOT RUN") and "DM_BENCH_BREAK_RCCL" in mg["rccl_error"]
+    assert len(mg["per_rank"]) == 1 and mg["per_rank"][0]["slice_sums"][0] == out["summary_check"]["touch"]
+
+
 def test_batched_reads_equal_per_read_calls(models, tmp_path, gpu_device):
     """mPredict_batch (one device call for many reads, concatenated feature matrices) must give exactly
     what the reference-granularity mPredict1 gives read by read."""

@@ -39,7 +39,7 @@ if __name__ == "__main__":
         cmd = [sys.executable, os.path.join(ROOT, "bin", "DeepMod.py"), "detect", "--wrkBase", wrk, "--modfile", prefix, "--outFolder",
                "%s/out%d" % (tmp, rep), "--Base", "C", "--gpus", "1", "--threads", str(nf), "--FileID", "s"] + sys.argv[3:]
         if os.environ.get("DM_E2E_PROF") and rep:                # kernel trace of the rank process(es): where the GPU time goes
-            cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", "%s/f%d" % (os.environ["DM_E2E_PROF"], nf), "--"] + cmd
+            cmd = ["rocprofv3", "--kernel-trace", "--memory-copy-trace", "--stats", "--output-format", "csv", "-d", "%s/f%d" % (os.environ["DM_E2E_PROF"], nf), "--"] + cmd
         t0 = time.time()
         res = subprocess.run(cmd, capture_output=True, text=True)
         wall = time.time() - t0

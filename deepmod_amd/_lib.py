@@ -50,6 +50,7 @@ SIGNATURES = [
     ("dm_memcpy_h2d", _c.c_int, [_c.c_int, _vp, _vp, _c.c_size_t]),
     ("dm_memcpy_d2h", _c.c_int, [_c.c_int, _vp, _vp, _c.c_size_t]),
     ("dm_model_h2d_async", _c.c_int, [_vp, _vp, _vp, _c.c_size_t]),
+    ("dm_model_h2d_ahead", _c.c_int, [_vp, _vp, _vp, _c.c_size_t]),
     ("dm_host_alloc", _vp, [_c.c_int, _c.c_size_t]),
     ("dm_host_free", _c.c_int, [_c.c_int, _vp]),
     ("dm_model_mark", _c.c_int, [_vp, _c.c_int]),

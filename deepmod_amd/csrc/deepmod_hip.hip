@@ -459,6 +459,9 @@ struct dm_model {
     float* d_x = nullptr;
     float* d_x2 = nullptr;       // second staging buffer: H2D of batch i+1 overlaps the kernel of batch i
     hipStream_t copy_stream = nullptr;
+    static constexpr int AHEAD_EVENTS = 8;      // dm_model_h2d_ahead: copy-done events, reused round robin (a wait captures the record it was queued behind)
+    hipEvent_t ahead_event[AHEAD_EVENTS] = {};
+    int ahead_next = 0;
     float* d_prob = nullptr;
     uint8_t* d_cls = nullptr;
     int64_t stage_rows = 0;  // capacity of d_x in floats
@@ -955,6 +958,8 @@ void dm_model_destroy(dm_model* m) {
     (void)hipFree(m->d_plogit);
     (void)hipFree(m->d_x);
     (void)hipFree(m->d_x2);
+    for (hipEvent_t ev : m->ahead_event)
+        if (ev) (void)hipEventDestroy(ev);
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
     if (m->range_flag) (void)hipHostFree(m->range_flag);
     (void)hipFree(m->d_prob);
@@ -1159,6 +1164,23 @@ int dm_model_h2d_async(dm_model* m, void* dst, const void* src, size_t bytes) {
     if (!dst || !src) return fail(DM_EINVAL, "null buffer");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m->stream));
+    return DM_OK;
+}
+
+// host -> device copy on the model's COPY stream: it does not wait for the launches already queued (it overlaps them), and
+// every launch queued after this call waits for it.  The caller guarantees that nothing queued touches dst (a marker passed).
+int dm_model_h2d_ahead(dm_model* m, void* dst, const void* src, size_t bytes) {
+    if (!m) return fail(DM_EINVAL, "null model");
+    if (bytes == 0) return DM_OK;
+    if (!dst || !src) return fail(DM_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+    hipEvent_t& ev = m->ahead_event[m->ahead_next];
+    if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    m->ahead_next = (m->ahead_next + 1) % dm_model::AHEAD_EVENTS;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m->copy_stream));
+    HIP_TRY(hipEventRecord(ev, m->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(m->stream, ev, 0));
     return DM_OK;
 }
 

@@ -844,6 +844,7 @@ class HipBackend:
         self._dm = dm
         self._sets = [{'host': None, 'dev': None} for _ in range(self.NSET)]
         self._k = 0
+        self._h2d = self._lib.dm_model_h2d_ahead if int(os.environ.get('DEEPMOD_COPY_AHEAD', 1)) else self._lib.dm_model_h2d_async
         self.timing = defaultdict(float)   # where submit() spends the GPU process' time
 
     def _staging(self, st, nbytes):
@@ -891,7 +892,9 @@ class HipBackend:
             pb.on_done()
             pb.on_done = None
         t2 = time.perf_counter()
-        self._lib_check(self._lib.dm_model_h2d_async(self.model._h, dev.ptr, host.ptr, end))
+        # on the copy stream: the upload of this batch runs while the device classifies the batches before it (nothing queued reads
+        # this set: its marker has passed), and the launches below wait for it
+        self._lib_check(self._h2d(self.model._h, dev.ptr, host.ptr, end))
         d_rows, d_pos, d_flags, d_cls, d_sel = dev.ptr, dev.ptr + o_pos, dev.ptr + o_flags, dev.ptr + o_cls, dev.ptr + o_sel
         if pb.sel is None:
             # classic form: window centred on row r -> cls[r]; rows 0..9 and R-10..R-1 are padding of the first / last read

@@ -156,6 +156,10 @@ int dm_memcpy_d2h(int device, void* dst, const void* src, size_t bytes);
 /* host -> device copy queued on the model's stream (ordered with its launches; with DM_OPT_ASYNC a worker refills its
  * staging buffers without waiting for the device).  src must stay valid until the next dm_model_sync. */
 int dm_model_h2d_async(dm_model* m, void* dst, const void* src, size_t bytes);
+/* The same copy on the model's copy stream: it does NOT wait for the launches already queued (it runs while they compute) and
+ * every launch queued after this call waits for it.  The caller guarantees that no queued launch touches dst - in the staging
+ * scheme below: dm_model_wait_mark of the set has returned.  src must stay valid until the set's next marker has passed. */
+int dm_model_h2d_ahead(dm_model* m, void* dst, const void* src, size_t bytes);
 /* Page-locked host staging memory (hipHostMalloc) and stream markers for a pipelined worker: batch k is copied into staging
  * set k % N while the device still works on batch k - 1; dm_model_mark(m, i) records a marker on the model's stream after the
  * launches that read set i, dm_model_wait_mark(m, i) blocks the host until that marker has passed (at once if it was never

@@ -9,11 +9,13 @@ from deepmod_amd import _lib, model, synth
 pytestmark = pytest.mark.gpu
 
 
-def test_pipelined_staging_sets_equal_synchronous_calls(gpu_device):
+@pytest.mark.parametrize("copy", ["dm_model_h2d_async", "dm_model_h2d_ahead"])
+def test_pipelined_staging_sets_equal_synchronous_calls(gpu_device, copy):
     w = synth.synthetic_weights(26, 4.0)
     m = model.BiLSTMModel(w, device=gpu_device)
     rng = np.random.default_rng(5)
-    batches = [synth.synthetic_windows(n, seed=int(s))[:, 10, :].copy() for n, s in ((5000, 1), (777, 2), (12001, 3), (64, 4), (3000, 5), (9000, 6))]
+    batches = [synth.synthetic_windows(n, seed=int(s))[:, 10, :].copy() for n, s in ((5000, 1), (777, 2), (12001, 3), (64, 4), (3000, 5), (9000, 6), (120000, 7), (90, 8),
+                                                                                        (100000, 9), (64, 10), (110000, 11), (30, 12))]
     want = [m.predict_read(rows, 10, len(rows) - 20, want_prob=False)[1] for rows in batches]
 
     m.set_option(_lib.DM_OPT_ASYNC, 1)
@@ -27,7 +29,7 @@ def test_pipelined_staging_sets_equal_synchronous_calls(gpu_device):
         i = k % nset
         m.wait_mark(i)                                   # never recorded for the first nset batches: returns at once
         host[i].view(np.float32, rows.size)[:] = rows.ravel()
-        _lib.check(lib.dm_model_h2d_async(m._h, dev[i].ptr, host[i].ptr, rows.nbytes))
+        _lib.check(getattr(lib, copy)(m._h, dev[i].ptr, host[i].ptr, rows.nbytes))      # in stream order / on the copy stream, ahead of the queue
         m.predict_rows_device(dev[i].ptr, len(rows), 10, len(rows) - 20, cls[k].ptr + 10)
         m.mark(i)
     for i in range(nset):

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import glob
 import multiprocessing
+import multiprocessing.connection
 import os
 import time
 from collections import defaultdict
@@ -467,6 +468,26 @@ def plan_batches(files, per_batch):
             for i in range(0, len(files), per_batch)]
 
 
+def plan_batches_sized(files, per_batch, max_bytes):
+    """The work items of a streaming run: consecutive inputs, at most `per_batch` of them and at most `max_bytes` of input per batch
+    (one input always fits) - a feeder hands a batch over in one shared-memory slot, and a batch that outgrows the slot takes the slow
+    way through a file of its own (stream.StreamEngine.run_processes)."""
+    items, cur, cur_bytes = [], [], 0
+    for f in files:
+        try:
+            size = os.path.getsize(f)
+        except OSError:
+            size = 0                                    # (the feeder reports the unreadable input)
+        if cur and (len(cur) >= per_batch or cur_bytes + size > max_bytes):
+            items.append((cur, len(items) // SUBFOLDER_BATCHES, len(items)))
+            cur, cur_bytes = [], 0
+        cur.append(f)
+        cur_bytes += size
+    if cur:
+        items.append((cur, len(items) // SUBFOLDER_BATCHES, len(items)))
+    return items
+
+
 def _run_processes(ctx, target, argsets, what, poll=None):
     """Start one process per argument tuple, call `poll()` while they run, fail loudly if one dies."""
     procs = [ctx.Process(target=target, args=a) for a in argsets]
@@ -481,7 +502,7 @@ def _run_processes(ctx, target, argsets, what, poll=None):
                     p.terminate()
             break
         if poll is None or not poll():
-            time.sleep(0.02)
+            multiprocessing.connection.wait([p.sentinel for p in procs], timeout=0.02)      # returns the moment one of them ends
     for p in procs:
         p.join()
     if any(p.exitcode != 0 for p in procs):
@@ -541,9 +562,8 @@ def _run_streaming_detect(moptions, ctx, pmanager, items, ngpu):
     (deepmod_amd/stream.py).  -> (error ledger, per-rank stats)"""
     from . import stream
     world = max(1, min(ngpu, len(items)))
-    work_q, result_q = pmanager.Queue(), pmanager.Queue()
-    for it in items:
-        work_q.put(it)
+    # (no manager process on this path: the items are known, a shared counter hands them out - stream.WorkList)
+    work_q, result_q = stream.WorkList(items, ctx), ctx.Queue()
     run_opts = dict(moptions, outFolder=moptions['outFolder'] + moptions['FileID'])
     rdv = os.path.join(run_opts['outFolder'], '.rendezvous')
     if os.path.isdir(rdv):
@@ -559,17 +579,22 @@ def _run_streaming_detect(moptions, ctx, pmanager, items, ngpu):
     from . import rawreads
     if not run_opts.get('signal_server', True) and any(f.endswith(rawreads.RAW_SUFFIX) for it in items for f in it[0]):
         feeder_procs = min(feeder_procs, int(moptions.get('feeder_procs_raw', 8)))
-    _run_processes(ctx, stream.stream_rank_main,
-                   [(run_opts, r, world, r, work_q, result_q, feeders, feeder_procs) for r in range(world)], 'streaming detect')
     ledger, stats = defaultdict(list), []
-    while True:
+
+    def collect():          # while the ranks run: a rank's report may be larger than the pipe holds, and it ends only once it is read
         try:
             res = result_q.get(block=False)
         except Exception:
-            break
+            return False
         for reason, files in res['errors'].items():
             ledger[reason].extend(files)
         stats.append(res['stats'])
+        return True
+
+    _run_processes(ctx, stream.stream_rank_main,
+                   [(run_opts, r, world, r, work_q, result_q, feeders, feeder_procs) for r in range(world)], 'streaming detect', collect)
+    while collect():
+        pass
     if len(stats) != world:
         raise RuntimeError('streaming detect: %d of %d ranks reported' % (len(stats), world))
     return ledger, stats
@@ -578,7 +603,7 @@ def _run_streaming_detect(moptions, ctx, pmanager, items, ngpu):
 _BASE_OF_RUN = ['?']
 
 
-def _print_stream_stats(stats, wall):
+def _print_stream_stats(stats, wall, since_start=None):
     tot = defaultdict(float)
     for st in stats:
         for k, v in st.items():
@@ -594,8 +619,8 @@ def _print_stream_stats(stats, wall):
     busy = sum(host.values()) + tot['submit']
     parts = ['%s %.0f%%' % (k, 100 * v / max(busy, 1e-9)) for k, v in sorted(host.items(), key=lambda kv: -kv[1])]
     print('\thost stages (share of feeder + submit time): ' + ', '.join(parts) + ', device submit %.0f%%' % (100 * tot['submit'] / max(busy, 1e-9))
-          + '; detect wall %.1f s, waiting for feeders %.1f s, merge + BED %.1f s per rank'
-          % (tot['detect_wall'] / len(stats), tot['wait_feed'] / len(stats), tot['merge+bed'] / len(stats))
+          + '; %d batches (%d handed over in shared-memory slots); detect wall %.1f s, waiting for feeders %.1f s, merge + BED %.1f s per rank'
+          % (tot['batches'], tot['slot_batches'], tot['detect_wall'] / len(stats), tot['wait_feed'] / len(stats), tot['merge+bed'] / len(stats))
           + '; device queue: waiting for the device %.1f s, staging copy %.1f s, launches %.1f s'
           % (tot['submit_wait_device'] / len(stats), tot['submit_stage'] / len(stats), tot['submit_launch'] / len(stats))
           + ('; signal server %.1f s (%.1f s inside dm_signal_event_stats_batch) for %d requests'
@@ -603,9 +628,9 @@ def _print_stream_stats(stats, wall):
     if 'at_rank_start' in tot and 'at_drained' in tot:
         n, r0 = len(stats), tot['at_rank_start'] / len(stats)
         print('\ttimeline, seconds after the command began its detect step (mean over ranks): GPU process running %.2f, model on the device %.2f, '
-              'first batch from a feeder %.2f, last batch %.2f, device drained %.2f, BED written and process done %.2f'
+              'first batch from a feeder %.2f, last batch %.2f, device drained %.2f, feeders gone %.2f, BED written %.2f, process done %.2f, processes joined %.2f'
               % (r0, r0 + tot['at_backend_ready'] / n, r0 + tot['at_first_batch'] / n, r0 + tot['at_last_batch'] / n, r0 + tot['at_drained'] / n,
-                 tot['at_rank_end'] / n))
+                 r0 + tot['at_feeders_gone'] / n, tot['at_bed_written'] / n, tot['at_rank_end'] / n, wall if since_start is None else since_start))
 
 
 def _run_summary_jobs(moptions, ctx, pmanager, ngpu):
@@ -625,6 +650,18 @@ def _worker_entry(target, args, device):
     target(*args, device=device)
 
 
+class _LazyManager:
+    """ctx.Manager() on first use: a streaming run never needs one."""
+
+    def __init__(self, ctx):
+        self._ctx, self._m = ctx, None
+
+    def Queue(self):
+        if self._m is None:
+            self._m = self._ctx.Manager()
+        return self._m.Queue()
+
+
 def mDetect_manager(moptions):
     """The detect run (counterpart of myDetect.py:1124-1263): inputs -> worker batches -> detect -> per-position summary
     -> `<outFolder>.done`.  predDet == 1 runs the streaming mode unless `storePred` asks for the reference's per-read
@@ -635,7 +672,7 @@ def mDetect_manager(moptions):
         raise NotImplementedError("--mod_cluster 1 is not built (the reference marks that branch 'should not used now', myDetect.py:1054)")
     moptions['_t_manager'] = time.time()
     ctx = multiprocessing.get_context('spawn')      # never fork a process that may hold a HIP context
-    pmanager = ctx.Manager()
+    pmanager = _LazyManager(ctx)       # the stored-prediction paths share their queues through a manager like the reference (myDetect.py:1141)
     ngpu = max(1, int(moptions.get('gpus', 1)))
     moptions['threads'] = max(1, int(moptions['threads']))
     if moptions.get('wrkBase'):
@@ -656,11 +693,14 @@ def mDetect_manager(moptions):
             # counters are sums, so the BED does not depend on it. The reference's default (1000 single-read FAST5 files) would put
             # a whole run of multi-read containers into ONE batch and leave all feeders but one idle: keep >= 8 batches per feeder
             per_batch = max(1, min(per_batch, -(-len(files) // (8 * moptions['threads']))))
-        items = plan_batches(files, per_batch)
+        if streamed:       # (feature rows are no larger than the containers they come from: a batch of <= 0.8 slot of input fits its slot)
+            items = plan_batches_sized(files, per_batch, int(0.8 * (int(moptions.get('feeder_slot_mb', 128)) << 20)))
+        else:
+            items = plan_batches(files, per_batch)
         if streamed:
             _BASE_OF_RUN[0] = moptions['Base']
             ledger, stats = _run_streaming_detect(moptions, ctx, pmanager, items, ngpu)
-            _print_stream_stats(stats, time.time() - t0)
+            _print_stream_stats(stats, time.time() - t0, time.time() - moptions['_t_manager'])
         else:
             ledger = _run_stored_detect(moptions, ctx, pmanager, items, ngpu)
             moptions['predpath'] = moptions['outFolder'] + '/' + moptions['FileID']

@@ -1136,6 +1136,7 @@ class StreamEngine:
                 for th in server:
                     th.join(timeout=10)
             shutil.rmtree(shm_dir, ignore_errors=True)
+        self.stats['at_feeders_gone'] = time.perf_counter() - t_start
         self.stats['detect_wall'] += time.perf_counter() - t_start
         for k, v in getattr(self.backend, 'timing', {}).items():
             self.stats['submit_' + k] += v
@@ -1159,6 +1160,27 @@ class StreamEngine:
         # (moptions['force_scatter_merge']: the scatter form on a single rank too - how the GPU tests run this code path on one GPU)
         scattered = scatter_fn is not None and (self.world > 1 or bool(self.mo.get('force_scatter_merge')))
         out_path = lambda chrom, strand: '%s/mod_pos.%s%s.%s.bed' % (self.mo['outFolder'], chrom, strand, self.mo['Base'])
+        def fetch_format_write(key):             # one rank, one table: download the counters, format, write (all outside the interpreter lock)
+            chrom, strand = key.split("\t")
+            s = self.summaries[(chrom, strand)]
+            touch, cov, mod = s.fetch()
+            bed = dmsum.bed_lines(chrom, strand, self.mo['Base'], touch, cov, mod)
+            if write and len(bed) > 0:              # the reference writes no file for an empty table (myDetect.py:1109)
+                with open(out_path(chrom, strand), 'wb') as fh:
+                    fh.write(bed)
+            s.close()
+            return bed
+
+        if not scattered and self.world == 1 and len(keys) > 1:
+            # a single rank: the tables are independent (own counters, own stream, own file) - contig x strand tables side by side
+            from concurrent.futures import ThreadPoolExecutor
+            for key in keys:
+                chrom, strand = key.split("\t")
+                self.summaries[(chrom, strand)].grow(max(self.summaries[(chrom, strand)].length, lens.get(chrom, 0)))
+            with ThreadPoolExecutor(min(4, len(keys))) as pool:
+                for key, bed in zip(keys, pool.map(fetch_format_write, keys)):
+                    beds[tuple(key.split("\t"))] = bed
+            keys = []
         for key in keys:
             chrom, strand = key.split("\t")
             length = max([e["keys"].get(key, 0) for e in everyone] + [e["len"].get(chrom, 0) for e in everyone])
@@ -1218,6 +1240,28 @@ class StreamEngine:
 # ---------------------------------------------------------------------------------------------
 # process entry: one rank = one GPU
 # ---------------------------------------------------------------------------------------------
+class WorkList:
+    """The work items of one run, known before its processes start, handed out through one shared counter: what the feeders
+    and ranks of a streaming run take their batches from.  Same calls as the reference's h5files_Q (`get(block=False)`, queue.Empty
+    when nothing is left), without a manager process in between (0.2 s of start-up and shut-down on a 2 s run) and without the
+    window in which a multiprocessing.Queue that was filled a moment ago still reads as empty."""
+
+    def __init__(self, items, ctx):
+        self.items = list(items)
+        self.head = ctx.Value('q', 0)
+
+    def get(self, block: bool = False):
+        with self.head.get_lock():
+            i = self.head.value
+            if i >= len(self.items):
+                raise queue.Empty
+            self.head.value = i + 1
+        return self.items[i]
+
+    def empty(self) -> bool:
+        return self.head.value >= len(self.items)
+
+
 def _drain(q):
     while True:
         try:
@@ -1269,6 +1313,8 @@ def _stream_rank_body(moptions, rank, world, device, work, result_q, feeders, fe
     else:
         gather = scatter_fn = None
     eng.finalize(gather, scatter_fn)
+    if moptions.get('_t_manager'):
+        eng.stats['at_bed_written'] = time.time() - moptions['_t_manager']
     if communicator is not None:
         eng.stats.update({'comm_' + k: v for k, v in communicator.stats().items()})
         communicator.close()

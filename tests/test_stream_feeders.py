@@ -290,3 +290,38 @@ def test_compact_batch_without_any_base_of_interest(tmp_path):
     eng.consume(got)
     beds = eng.finalize(None, None)
     assert all(len(b) == 0 for b in beds.values()) and not [f for f in os.listdir(mo['outFolder']) if f.endswith('.bed')]
+
+
+def _take_all(work, out_q, wid):
+    import queue as _q
+    got = []
+    while True:
+        try:
+            got.append(work.get(block=False))
+        except _q.Empty:
+            break
+    out_q.put((wid, got))
+
+
+def test_work_list_hands_every_item_out_once_across_processes():
+    """stream.WorkList (the streaming run's h5files_Q without a manager process): spawned processes draining it together get
+    every item exactly once, and an exhausted list answers queue.Empty like the reference's `get(block=False)`."""
+    import multiprocessing
+    import queue as _q
+    import pytest
+    from deepmod_amd import stream
+    ctx = multiprocessing.get_context('spawn')
+    items = [(['f%d_%d' % (i, j) for j in range(3)], i // 100, i) for i in range(500)]
+    work = stream.WorkList(items, ctx)
+    out_q = ctx.Queue()
+    procs = [ctx.Process(target=_take_all, args=(work, out_q, w)) for w in range(3)]
+    for p in procs:
+        p.start()
+    got = [out_q.get(timeout=60) for _ in procs]
+    for p in procs:
+        p.join()
+    flat = sorted((it for _, g in got for it in g), key=lambda it: it[2])
+    assert flat == items
+    assert work.empty()
+    with pytest.raises(_q.Empty):
+        work.get(block=False)

@@ -31,7 +31,7 @@ if __name__ == "__main__":
     os.makedirs(tmp + "/model")
     synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)
     cmd = [sys.executable, os.path.join(ROOT, "bin", "DeepMod.py"), "detect", "--wrkBase", wrk, "--Ref", wrk + "/genome.fa", "--modfile", prefix,
-           "--outFolder", tmp + "/out", "--Base", "C", "--gpus", "1", "--threads", str(threads), "--files_per_thread", "4", "--FileID", "raw", "--alignStr", "minimap2"] + sys.argv[3:]
+           "--outFolder", tmp + "/out", "--Base", "C", "--gpus", "1", "--threads", str(threads), "--FileID", "raw", "--alignStr", "minimap2"] + sys.argv[3:]
     t0 = time.time()
     res = subprocess.run(cmd, capture_output=True, text=True)
     wall = time.time() - t0
@@ -39,6 +39,6 @@ if __name__ == "__main__":
         print(res.stdout[-2000:], res.stderr[-3000:])
         sys.exit(1)
     for ln in res.stdout.splitlines():
-        if "Streaming detect" in ln or "host stages" in ln:
+        if "Streaming detect" in ln or "host stages" in ln or "timeline" in ln:
             print(ln.strip())
     print("raw containers -> BED: %d feeder threads, whole command %.1f s" % (threads, wall))

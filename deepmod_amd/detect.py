@@ -627,9 +627,9 @@ def _print_stream_stats(stats, wall, since_start=None):
              % (tot['signal_server'] / len(stats), tot['signal_server_call'] / len(stats), tot['signal_requests']) if tot['signal_requests'] else ''))
     if 'at_rank_start' in tot and 'at_drained' in tot:
         n, r0 = len(stats), tot['at_rank_start'] / len(stats)
-        print('\ttimeline, seconds after the command began its detect step (mean over ranks): GPU process running %.2f, model on the device %.2f, '
+        print('\ttimeline, seconds after the command began its detect step (mean over ranks): GPU process running %.2f, feeder processes started %.2f, model on the device %.2f, '
               'first batch from a feeder %.2f, last batch %.2f, device drained %.2f, feeders gone %.2f, BED written %.2f, process done %.2f, processes joined %.2f'
-              % (r0, r0 + tot['at_backend_ready'] / n, r0 + tot['at_first_batch'] / n, r0 + tot['at_last_batch'] / n, r0 + tot['at_drained'] / n,
+              % (r0, r0 + tot['at_feeders_started'] / n, r0 + tot['at_backend_ready'] / n, r0 + tot['at_first_batch'] / n, r0 + tot['at_last_batch'] / n, r0 + tot['at_drained'] / n,
                  r0 + tot['at_feeders_gone'] / n, tot['at_bed_written'] / n, tot['at_rank_end'] / n, wall if since_start is None else since_start))
 
 

@@ -1088,6 +1088,7 @@ class StreamEngine:
                                    sig_answers[i] if sig_answers else None)) for i in range(n_procs)]
         for pr in procs:
             pr.start()
+        self.stats['at_feeders_started'] = time.perf_counter() - t_start
         clean = False
         try:
             if make_backend is not None:

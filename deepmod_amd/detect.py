@@ -591,8 +591,11 @@ def _run_streaming_detect(moptions, ctx, pmanager, items, ngpu):
         stats.append(res['stats'])
         return True
 
-    _run_processes(ctx, stream.stream_rank_main,
-                   [(run_opts, r, world, r, work_q, result_q, feeders, feeder_procs) for r in range(world)], 'streaming detect', collect)
+    try:
+        _run_processes(ctx, stream.stream_rank_main,
+                       [(run_opts, r, world, r, work_q, result_q, feeders, feeder_procs) for r in range(world)], 'streaming detect', collect)
+    finally:
+        work_q.close()
     while collect():
         pass
     if len(stats) != world:

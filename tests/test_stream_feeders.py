@@ -325,3 +325,6 @@ def test_work_list_hands_every_item_out_once_across_processes():
     assert work.empty()
     with pytest.raises(_q.Empty):
         work.get(block=False)
+    assert os.path.exists(work.path)
+    work.close()
+    assert not os.path.exists(work.path)

@@ -388,15 +388,23 @@ def summarize_tables(tables, base: str, device: int = 0, length=None, chunk_rows
         pend_p, pend_f, pending = [], [], 0
 
     for m_pred in tables:
-        if len(m_pred) == 0:
-            continue
-        fl = base_flags(m_pred, base)
-        keep = (fl & 1) != 0
-        if not keep.any():
-            continue
-        pend_p.append(m_pred['refbasei'][keep].astype(np.int64))
-        pend_f.append(fl[keep])
-        pending += int(keep.sum())
+        if isinstance(m_pred, tuple):           # (positions, flags) of rows on the base of interest: stored_chunks
+            p, f = m_pred
+            if len(p) == 0:
+                continue
+            pend_p.append(p)
+            pend_f.append(f)
+            pending += len(p)
+        else:
+            if len(m_pred) == 0:
+                continue
+            fl = base_flags(m_pred, base)
+            keep = (fl & 1) != 0
+            if not keep.any():
+                continue
+            pend_p.append(m_pred['refbasei'][keep].astype(np.int64))
+            pend_f.append(fl[keep])
+            pending += int(keep.sum())
         if pending >= chunk_rows:
             flush()
     flush()
@@ -409,6 +417,50 @@ def summarize_tables(tables, base: str, device: int = 0, length=None, chunk_rows
         last = int(np.flatnonzero(touch).max()) + 1 if touch.any() else 0
         touch, cov, mod = touch[:last], cov[:last], mod[:last]
     return touch, cov, mod
+
+
+def stored_chunks(moptions, sp_options, cur_chr, cur_strand, base, readers: int = 4):
+    """The records of sp_options['handlingList'] as (positions int64, flags uint8) chunks of the rows on `base` - what
+    summarize_tables makes of the tables read_pred_detail returns, without building them: one chunk per prediction store (format 2:
+    five members inflated per batch, the flags of all its reads in one pass over bytes).  Stores are inflated by `readers` threads
+    ahead of the consumer (zlib releases the interpreter lock).  A format-1 store goes read by read through read_pred_detail."""
+    from concurrent.futures import ThreadPoolExecutor
+    by_store = {}
+    for hl in sp_options['handlingList']:
+        by_store.setdefault(hl[5], []).append(hl)
+    base_code = ord(base) if base not in ('-', 'N', 'n') else -1
+
+    def one(rel):
+        st = predstore.load_pred_store(os.path.join(sp_options['base_folder_output'], rel))
+        if st['format'] == 1:
+            return [read_pred_detail(moptions, sp_options, hl) for hl in by_store[rel]]
+        spans = []
+        for hl in by_store[rel]:
+            at = st['attrs'][hl[3]]
+            if not (at['mapped_chr'] == cur_chr and at['mapped_strand'] == cur_strand):
+                print("ERRoR not the same chr (real=%s vs expect=%s) and strand (real=%s VS expect=%s)" %
+                      (at['mapped_chr'], cur_chr, at['mapped_strand'], cur_strand))
+            spans.append(predstore.pred_rows(st, hl[3]))
+        if not spans:
+            return (np.zeros(0, np.int64), np.zeros(0, np.uint8))
+        rows = np.concatenate([np.arange(lo, hi, dtype=np.int64) for lo, hi in spans])
+        refb = st['refbase'].view(np.uint8)[rows]
+        on_base = (refb == base_code) if base_code >= 0 else np.zeros(len(rows), bool)
+        rows = rows[on_base]
+        fl = (np.uint8(1) | ((st['readbase'].view(np.uint8)[rows] != 45).astype(np.uint8) << 1)
+              | ((st['mod_pred'][rows] == 1).astype(np.uint8) << 2))
+        return (st['refbasei'][rows].astype(np.int64), fl)
+
+    with ThreadPoolExecutor(max(1, readers)) as pool:
+        for out in pool.map(one, list(by_store)):
+            if isinstance(out, list):
+                for m_pred, mapped_chrom, mapped_strand in out:
+                    if not (mapped_chrom == cur_chr and mapped_strand == cur_strand):
+                        print("ERRoR not the same chr (real=%s vs expect=%s) and strand (real=%s VS expect=%s)" %
+                              (mapped_chrom, cur_chr, mapped_strand, cur_strand))
+                    yield m_pred
+            else:
+                yield out
 
 
 def sum_handler(moptions, chr_strand_Q, device=0):
@@ -427,15 +479,7 @@ def sum_handler(moptions, chr_strand_Q, device=0):
         nak = moptions['Base']
         outfile = '%s/mod_pos.%s%s.%s.bed' % (moptions['outFolder'], cur_chr, cur_strand, nak)
 
-        def tables():
-            for hl in sp_options['handlingList']:
-                m_pred, mapped_chrom, mapped_strand = read_pred_detail(moptions, sp_options, hl)
-                if not (mapped_chrom == cur_chr and mapped_strand == cur_strand):
-                    print("ERRoR not the same chr (real=%s vs expect=%s) and strand (real=%s VS expect=%s)" %
-                          (mapped_chrom, cur_chr, mapped_strand, cur_strand))
-                yield m_pred
-
-        touch, cov, mod = summarize_tables(tables(), nak, device)
+        touch, cov, mod = summarize_tables(stored_chunks(moptions, sp_options, cur_chr, cur_strand, nak), nak, device)
         if moptions.get('outLevel', OUTPUT_WARNING) <= OUTPUT_INFO:
             print('====sum done! To save')
             print('\tSave %s' % outfile)

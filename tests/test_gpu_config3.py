@@ -68,7 +68,7 @@ def test_config3_full_size_streaming_equals_stored_and_oracle(tmp_path, gpu_devi
     w = synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)
     out = str(tmp_path / 'out')
     base_args = ['--wrkBase', wrk, '--modfile', prefix, '--outFolder', out, '--Base', 'C', '--gpus', '1']
-    common = base_args + ['--files_per_thread', '4', '--threads', str(ncpu)]
+    common = base_args + ['--files_per_thread', '4', '--threads', str(min(8, ncpu))]      # (stored path: every worker owns a HIP context; beyond ~8 per GPU they slow each other down)
     # the streaming run gets TWO feeder processes and otherwise the command's defaults (round 3: the rows of a batch are built by
     # one pass of compiled code, dm_rows_*, batches are cut to fit the shared-memory slots and uploads run on a copy stream; round 2
     # needed 15 feeders to keep one GPU busy) - eight GPUs of a node then need 16 + 8 host cores, not 120

@@ -216,3 +216,55 @@ def test_npzmap_views_equal_numpy_load(tmp_path):
         assert not aligned[k].flags.writeable and aligned[k].ctypes.data % 64 == 0, k
     z = np.load(str(tmp_path / 'aligned.npz'))
     assert all(np.array_equal(z[k], v) for k, v in arrays.items())
+
+
+def test_stored_chunks_equal_the_per_read_tables(tmp_path):
+    """detect.stored_chunks (five members per prediction store, flags of all its reads in one pass over bytes) hands summarize_tables
+    the rows base_flags finds in the tables read_pred_detail builds read by read - for format-2 stores and for the per-read
+    members of format 1."""
+    from deepmod_amd import detect
+    rng = np.random.default_rng(3)
+    mo = {'outFolder': str(tmp_path) + '/', 'FileID': 'mod', 'Base': 'C'}
+    records, tables = [], {}
+    for batch in range(3):
+        w = predstore.PredWriter(str(tmp_path / 'mod' / '0'), batch)
+        old = {}
+        for r in range(5):
+            n = int(rng.integers(50, 400))
+            strand = '+-'[int(rng.integers(0, 2))]
+            bmi = predstore.make_base_map_info(rng.choice(list('ACGT-N'), n, p=[.23, .23, .23, .23, .04, .04]), rng.choice(list('ACGT-'), n),
+                                               np.sort(rng.integers(0, 5000, n)).astype(np.uint64), np.arange(n, dtype=np.uint64),
+                                               (rng.random(n) < 0.3).astype(int))
+            rd = {'readk': 'read%d_%d' % (batch, r), 'chr': 'chrS', 'strand': strand, 'mapped_start': 0, 'start_clip': 1, 'end_clip': 2}
+            key = w.add(rd, bmi, int(bmi['mod_pred'].sum()), 'x.dmfeat.npz', mo)
+            records.append(['chrS', strand, '0', key, 'x.dmfeat.npz', w.relpath(mo)])
+            tables[(w.relpath(mo), key)] = bmi
+            for f in ('refbase', 'readbase'):
+                old[key + '/' + f] = predstore.u1_to_s1(bmi[f])
+            old[key + '/refbasei'], old[key + '/readbasei'], old[key + '/mod_pred'] = bmi['refbasei'], bmi['readbasei'], bmi['mod_pred'].astype(np.int64)
+        w.close()
+        if batch == 1:              # the middle store in the per-read layout of format 1
+            old['attrs'] = np.array(json.dumps(w.attrs))
+            predstore.savez_fast(w.path, old)
+            assert predstore.load_pred_store(w.path)['format'] == 1
+        else:
+            assert predstore.load_pred_store(w.path)['format'] == 2
+    for strand in '+-':
+        sp = {'base_folder_output': str(tmp_path / 'mod') + '/', 'handlingList': [r for r in records if r[1] == strand]}
+        want = np.zeros((3, 5000), np.int64)
+        for r in sp['handlingList']:
+            bmi = tables[(r[5], r[3])]
+            fl = detect.base_flags(bmi, 'C')
+            for k in range(3):
+                np.add.at(want[k], bmi['refbasei'][(fl & 1) != 0].astype(np.int64), ((fl[(fl & 1) != 0] >> k) & 1))
+        got = np.zeros((3, 5000), np.int64)
+        for chunk in detect.stored_chunks(mo, sp, 'chrS', strand, 'C', readers=2):
+            if isinstance(chunk, tuple):
+                p, fl = chunk
+            else:
+                fl = detect.base_flags(chunk, 'C')
+                p, fl = chunk['refbasei'][(fl & 1) != 0].astype(np.int64), fl[(fl & 1) != 0]
+            assert (fl & 1).all()
+            for k in range(3):
+                np.add.at(got[k], p, (fl >> k) & 1)
+        assert np.array_equal(got, want) and want[0].sum() > 0

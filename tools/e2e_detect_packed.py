@@ -49,6 +49,6 @@ if __name__ == "__main__":
         if rep == 0:
             continue
         for ln in res.stdout.splitlines():
-            if "Streaming detect" in ln or "host stages" in ln or "timeline" in ln:
+            if "Streaming detect" in ln or "host stages" in ln or "timeline" in ln or "consuming time" in ln:
                 print("   ", ln.strip())
         print("%d feeder processes: whole command %.2f s" % (nf, wall), flush=True)

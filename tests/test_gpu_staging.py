@@ -16,6 +16,10 @@ def test_pipelined_staging_sets_equal_synchronous_calls(gpu_device, copy):
     rng = np.random.default_rng(5)
     batches = [synth.synthetic_windows(n, seed=int(s))[:, 10, :].copy() for n, s in ((5000, 1), (777, 2), (12001, 3), (64, 4), (3000, 5), (9000, 6), (120000, 7), (90, 8),
                                                                                         (100000, 9), (64, 10), (110000, 11), (30, 12))]
+    if copy == "dm_model_h2d_ahead":        # the copy stream runs ahead of the queue: many more batches of mixed sizes, sets reused ~30 times each
+        sizes = rng.integers(30, 150000, 80)
+        pool = synth.synthetic_windows(150000, seed=77)[:, 10, :].copy()
+        batches += [pool[int(o):int(o) + int(n)].copy() for n, o in zip(sizes, rng.integers(0, 150000 - sizes))]
     want = [m.predict_read(rows, 10, len(rows) - 20, want_prob=False)[1] for rows in batches]
 
     m.set_option(_lib.DM_OPT_ASYNC, 1)

@@ -86,13 +86,13 @@ SIGNATURES = [
     ("dm_map_read", _c.c_int, [_c.c_int, _i64, _c.c_char_p, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     ("dm_signal_event_stats", _c.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_i64), _vp]),
     ("dm_signal_event_stats_batch", _c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    ("dm_events_merge", _i64, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("dm_events_merge", _i64, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("dm_rows_create", _vp, [_c.c_char]),
     ("dm_rows_destroy", None, [_vp]),
-    ("dm_rows_add_packed", _c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    ("dm_rows_add_raw", _c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    ("dm_rows_add_packed", _c.c_int, [_vp, _i64, _i64, _i64, _i64, _c.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("dm_rows_add_raw", _c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _c.c_int32, _vp, _vp, _vp]),
-    ("dm_rows_add_mapped", _c.c_int, [_vp, _i64] + [_vp] * 16),
+    ("dm_rows_add_mapped", _c.c_int, [_vp, _i64, _i64, _i64, _c.c_int32] + [_vp] * 16),
     ("dm_rows_info", _i64, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64), _vp, _vp, _i64, _c.POINTER(_i64)]),
     ("dm_rows_emit", _i64, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32)]),
 ]

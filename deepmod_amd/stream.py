@@ -245,6 +245,8 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                     meta = json.loads(str(z['meta']))
                     n = len(meta)
                     eo = _c_arr(z['ev_off'], np.int64)
+                    if len(eo) != n + 1:
+                        raise ValueError('event offsets of a damaged container')
                     ne = int(eo[-1])
                     ms = _c_arr(z['ev_model_state'], z['ev_model_state'].dtype)
                     mev_off = np.empty(n + 1, np.int64)
@@ -253,11 +255,14 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                     args = [_c_arr(z['ev_mean'], np.float64), _c_arr(z['ev_stdv'], np.float64), _c_arr(z['ev_start'], np.uint64),
                             _c_arr(z['ev_length'], np.uint64)]
                     mv = _c_arr(z['ev_move'], np.int64)
-                    got = lib.dm_events_merge(n, eo.ctypes.data, args[0].ctypes.data, args[1].ctypes.data, args[2].ctypes.data, args[3].ctypes.data,
+                    got = lib.dm_events_merge(n, min(len(a) for a in args + [mv, ms]), eo.ctypes.data, args[0].ctypes.data, args[1].ctypes.data, args[2].ctypes.data, args[3].ctypes.data,
                                               ms.ctypes.data, ms.dtype.itemsize // 4, mv.ctypes.data, mev_off.ctypes.data, m_mean.ctypes.data,
                                               m_stdv.ctypes.data, m_start.ctypes.data, m_len.ctypes.data, m_base.ctypes.data)
                     if got < 0:
                         raise _lib.DeepModHipError(_lib.last_error())
+                    ro = _c_arr(z['raw_off'], np.int64)
+                    if len(ro) != n + 1 or ro[0] != 0 or (np.diff(ro) < 0).any() or ro[-1] > len(z['raw']):
+                        raise ValueError('signal offsets of a damaged container')
                 except Exception:
                     out.errors["Cannot open fast5 or other errors"].append(f5f)
                     print("Cannot open fast5 or other errors: {}".format(f5f))
@@ -271,7 +276,6 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                     ids.append(rid)
                     id_src.append(f5f)
                 raw_parts.append(z['raw'])
-                ro = _c_arr(z['raw_off'], np.int64)
                 raw_offs.extend((raw_offs[-1] + ro[1:]).tolist())
                 ev_offs.extend((ev_offs[-1] + mev_off[1:]).tolist())
                 cols['mean'].append(m_mean[:got]); cols['stdv'].append(m_stdv[:got]); cols['start'].append(m_start[:got])
@@ -344,7 +348,7 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                     keep.extend([flag, pos1, rlen, cidx, ev_read, skip, cig_b, seq_b, ref_ptr, ref_len, cig_ptr, seq_ptr, mev_off, m_mean, m_stdv,
                                  m_len, m_base, s_mean, s_stdv, first_empty, rg_c, rg_lo, rg_hi])
                     _lib.check(lib.dm_rows_add_raw(h, nrec, flag.ctypes.data, pos1.ctypes.data, cig_ptr, seq_ptr, rlen.ctypes.data, cidx.ctypes.data,
-                                                   ev_read.ctypes.data, skip.ctypes.data, nct, ref_ptr, ref_len.ctypes.data, len(mev_off) - 1, mev_off.ctypes.data,
+                                                   ev_read.ctypes.data, skip.ctypes.data, nct, ref_ptr, ref_len.ctypes.data, len(mev_off) - 1, len(m_mean), mev_off.ctypes.data,
                                                    m_mean.ctypes.data, m_stdv.ctypes.data, m_len.ctypes.data, m_base.ctypes.data, s_mean.ctypes.data,
                                                    s_stdv.ctypes.data, first_empty.ctypes.data, len(region), rg_c.ctypes.data, rg_lo.ctypes.data,
                                                    rg_hi.ctypes.data))
@@ -375,7 +379,12 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                         np.array([m['start_clip'] for m in meta], np.int64), np.array([m['end_clip'] for m in meta], np.int64),
                         np.array([contigs[m['chr']] for m in meta], np.int32), np.array([strands_c[m['strand']] for m in meta], np.int32)]
                 keep.append(arrs)
-                _lib.check(lib.dm_rows_add_packed(h, n, *[a.ctypes.data for a in arrs]))
+                n_tab = min(len(arrs[4]), len(arrs[5]), len(arrs[6]))
+                if (min(len(arrs[0]), len(arrs[1]), len(arrs[2])) != n + 1 or arrs[3].ndim != 2 or arrs[3].shape[1] != 7 or
+                        lib.dm_rows_add_packed(h, n, len(arrs[3]), n_tab, len(arrs[7]), len(contigs), *[a.ctypes.data for a in arrs]) != 0):
+                    # offset tables that do not fit their arrays (a truncated / damaged container): the file is reported, the batch goes on
+                    out.errors["Cannot open container"].append(cf)
+                    continue
                 srcs.extend([cf] * n)
             for c, ln in pk.get('contig_len', {}).items():
                 out.contig_len[c] = max(out.contig_len.get(c, 0), int(ln))

@@ -338,22 +338,26 @@ int dm_map_read(int flag, int64_t pos1, const char* cigar, const char* readseq, 
 #define DM_ROWS_NOT_MATCHING 7    /* raw reads: event bases differ from the table's read bases (:868-874) */
 #define DM_ROWS_INFO 8            /* int64 per read: status, contig, strand (0 '+', 1 '-'), windows, rows, table rows, mismatches, extras */
 typedef struct dm_rowsbatch dm_rowsbatch;
-int64_t dm_events_merge(int64_t n_reads, const int64_t* ev_off, const double* mean, const double* stdv, const uint64_t* start,
+/* Container tables come from disk: every offset table is checked against the size of the arrays it indexes (n_events, n_tx_rows,
+ * n_table_rows below), contigs against n_contigs, strands against {0, 1} - a damaged file is DM_EINVAL, never an out-of-bounds read
+ * (tests/test_asan_host.py drives these functions, built with -fsanitize=address, with damaged tables). */
+int64_t dm_events_merge(int64_t n_reads, int64_t n_events, const int64_t* ev_off, const double* mean, const double* stdv, const uint64_t* start,
                         const uint64_t* length, const uint32_t* model_state, int32_t ms_width, const int64_t* move, int64_t* mev_off,
                         float* m_mean, float* m_stdv, uint64_t* m_start, uint64_t* m_length, char* m_base);
 dm_rowsbatch* dm_rows_create(char base);
 void dm_rows_destroy(dm_rowsbatch* h);
-int dm_rows_add_packed(dm_rowsbatch* h, int64_t n_reads, const int64_t* row_off, const int64_t* bmi_off, const int64_t* ev_off,
+int dm_rows_add_packed(dm_rowsbatch* h, int64_t n_reads, int64_t n_tx_rows, int64_t n_table_rows, int64_t n_events, int32_t n_contigs,
+                       const int64_t* row_off, const int64_t* bmi_off, const int64_t* ev_off,
                        const float* tx, const char* refbase, const char* readbase, const int64_t* refbasei, const char* evbase,
                        const int64_t* start_clip, const int64_t* end_clip, const int32_t* contig, const int32_t* strand);
 int dm_rows_add_raw(dm_rowsbatch* h, int64_t n_reads, const int32_t* flag, const int64_t* pos1, const char* const* cigar,
                     const char* const* readseq, const int64_t* readseq_len, const int32_t* contig, const int32_t* ev_read,
                     const uint8_t* skip, int32_t n_contigs, const char* const* refseq, const int64_t* refseq_len,
-                    int64_t n_event_reads, const int64_t* mev_off, const float* m_mean, const float* m_stdv, const uint64_t* m_length, const char* m_base,
+                    int64_t n_event_reads, int64_t n_events, const int64_t* mev_off, const float* m_mean, const float* m_stdv, const uint64_t* m_length, const char* m_base,
                     const float* s_mean, const float* s_stdv, const int64_t* first_empty, int32_t n_region,
                     const int32_t* region_contig, const int64_t* region_lo, const int64_t* region_hi);
 /* reads whose alignment table the caller already has (get_Feature's rows are built from the event tables at emit time) */
-int dm_rows_add_mapped(dm_rowsbatch* h, int64_t n_reads, const int64_t* bmi_off, const char* refbase, const char* readbase,
+int dm_rows_add_mapped(dm_rowsbatch* h, int64_t n_reads, int64_t n_table_rows, int64_t n_events, int32_t n_contigs, const int64_t* bmi_off, const char* refbase, const char* readbase,
                        const int64_t* refbasei, const int64_t* start_clip, const int64_t* end_clip, const int32_t* contig,
                        const int32_t* strand, const int64_t* mev_off, const float* m_mean, const float* m_stdv, const uint64_t* m_length,
                        const char* m_base, const float* s_mean, const float* s_stdv, const int64_t* first_empty);

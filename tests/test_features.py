@@ -66,7 +66,7 @@ def test_compiled_feature_rows_match_reference_get_feature():
     h = lib.dm_rows_create(b'C')
     try:
         order = ('bmi_off', 'refb', 'readb', 'refi', 'sc', 'ec', 'contig', 'strand', 'mev_off', 'mean', 'stdv', 'length', 'base')
-        _lib.check(lib.dm_rows_add_mapped(h, n, *[arrs[k].ctypes.data for k in order], None, None, None))
+        _lib.check(lib.dm_rows_add_mapped(h, n, len(arrs['refb']), len(arrs['mean']), 1, *[arrs[k].ctypes.data for k in order], None, None, None))
         R, T, S = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         info = np.zeros((n, 8), np.int64)
         assert lib.dm_rows_info(h, ctypes.byref(R), ctypes.byref(T), ctypes.byref(S), info.ctypes.data, None, 0, None) == n

@@ -2,6 +2,7 @@
 StreamEngine.run_processes).  A batch prepared in a worker process and handed over through a shared-memory file must be the
 batch prepare_batch() builds in-process, and the engine fed by processes must produce the BED bytes of the engine fed by
 threads (device calls replaced by the oracle stand-in of tests/cpu_backend.py, as in test_stream_gloo.py)."""
+import json
 import multiprocessing
 import os
 import queue
@@ -328,3 +329,37 @@ def test_work_list_hands_every_item_out_once_across_processes():
     assert os.path.exists(work.path)
     work.close()
     assert not os.path.exists(work.path)
+
+
+def test_damaged_feature_container_is_reported_and_the_batch_goes_on(tmp_path):
+    """A packed feature container whose offset tables do not fit their columns (a truncated or damaged file): dm_rows_add_packed
+    refuses it as a whole (DM_EINVAL, checked against the column sizes the caller passes), the file goes to the error ledger and the
+    other containers of the batch are processed as if it were not there."""
+    from deepmod_amd import npzmap, predstore
+    files = synth_reads.write_synthetic_run(str(tmp_path / 'in'), n_reads=9, reads_per_file=3, genome_len=8000, seed=3, chrom='chrA',
+                                            min_len=200, max_len=600)
+    assert len(files) == 3
+    mo = {'Base': 'C', 'outFolder': str(tmp_path / 'out'), 'fnum': 7, 'hidden': 100, 'windowsize': 21}
+    os.makedirs(mo['outFolder'])
+    want = stream._prepare_batch_c(dict(mo), [files[0], files[2]])
+    for damage in ('offset past the column', 'decreasing offsets', 'truncated column', 'offset table too short'):
+        pk = predstore.load_packed(files[1])
+        z = {k: np.array(pk[k]) for k in ('tx', 'refbase', 'readbase', 'refbasei', 'evbase', 'row_off', 'bmi_off', 'ev_off')}
+        z['format'] = np.array(2)
+        z['meta'] = np.array(json.dumps({'reads': pk['reads'], 'contig_len': {}}))
+        if damage == 'offset past the column':
+            z['bmi_off'][-1] += 100000
+        elif damage == 'decreasing offsets':
+            z['row_off'][1], z['row_off'][2] = z['row_off'][2], z['row_off'][1]
+        elif damage == 'truncated column':
+            z['tx'] = z['tx'][:len(z['tx']) // 2]
+        else:
+            z['ev_off'] = z['ev_off'][:-1]
+        bad = str(tmp_path / 'in' / ('damaged' + predstore.CONTAINER_SUFFIX))
+        with open(bad, 'wb') as fh:
+            npzmap.savez_aligned(fh, **z)
+        got = stream._prepare_batch_c(dict(mo), [files[0], bad, files[2]])
+        assert got.errors.get("Cannot open container") == [bad], (damage, dict(got.errors))
+        assert got.n_reads == want.n_reads and got.n_rows == want.n_rows and got.groups == want.groups, damage
+        assert np.array_equal(got.rows, want.rows) and np.array_equal(got.pos, want.pos) and np.array_equal(got.flags, want.flags), damage
+        os.remove(bad)

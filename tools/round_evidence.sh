@@ -17,7 +17,9 @@ tools/ubench/mfma_i8 > $O/ubench_mfma_i8.txt 2>&1
 ( python tools/e2e_rate.py packed 200 | sed -n 2,2p; python tools/e2e_rate.py raw 200 | sed -n 2,2p; python tools/e2e_rate.py feat 60 | sed -n 2,2p;
   echo "-- the per-read Python path (DEEPMOD_ROWS_IN_C=0) on the same box:";
   DEEPMOD_ROWS_IN_C=0 python tools/e2e_rate.py packed 200 | sed -n 2,2p; DEEPMOD_ROWS_IN_C=0 python tools/e2e_rate.py raw 200 | sed -n 2,2p ) > $O/e2e_rate.txt 2>&1
-python tools/e2e_detect_raw.py 20000 4 > $O/e2e_detect_raw.txt 2>&1
+python tools/e2e_detect_raw.py 20000 4,4,6,8 > $O/e2e_detect_raw.txt 2>&1
+python tools/e2e_detect_packed.py 1,2,3,4 > $O/e2e_packed_feeders.txt 2>&1
+python tools/e2e_detect_packed.py 2,3,4 120 > $O/e2e_packed_120x.txt 2>&1
 for P in f16x3 f16i8 f32; do bash tools/power_trace.sh $O/power_$P.txt python tools/bench_loop.py $P 6 > /dev/null; done
 # energy per launch of timing-only builds of the default kernel (tools/ablate.py build base,s_nocell,s_nodma,s_nobar,s_prod2,s_b64,s_floor)
 : > $O/power_ablations.txt

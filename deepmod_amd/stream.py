@@ -1174,14 +1174,21 @@ class StreamEngine:
             chrom, strand = key.split("\t")
             s = self.summaries[(chrom, strand)]
             touch, cov, mod = s.fetch()
-            bed = dmsum.bed_lines(chrom, strand, self.mo['Base'], touch, cov, mod)
-            if write and len(bed) > 0:              # the reference writes no file for an empty table (myDetect.py:1109)
-                with open(out_path(chrom, strand), 'wb') as fh:
-                    fh.write(bed)
             s.close()
-            return bed
+            if not write:
+                return dmsum.bed_lines(chrom, strand, self.mo['Base'], touch, cov, mod)
+            # slices of the table formatted side by side and written in order; the text of a large contig is never held whole
+            fh = None
+            for part in dmsum.bed_parts(chrom, strand, self.mo['Base'], touch, cov, mod):
+                if fh is None:                      # the reference writes no file for an empty table (myDetect.py:1109)
+                    fh = open(out_path(chrom, strand), 'wb')
+                fh.write(part)
+                self.stats['bed_bytes'] += len(part)
+            if fh is not None:
+                fh.close()
+            return b'' if fh is None else None      # None: written to its file
 
-        if not scattered and self.world == 1 and len(keys) > 1:
+        if not scattered and self.world == 1 and len(keys) >= 1:
             # a single rank: the tables are independent (own counters, own stream, own file) - contig x strand tables side by side
             from concurrent.futures import ThreadPoolExecutor
             for key in keys:
@@ -1202,14 +1209,17 @@ class StreamEngine:
                 s.sync()                                # every rank: positions this rank dropped as out of range fail the run here
                 first, count = scatter_fn(s)
                 touch, cov, mod = s.fetch_slice()
-                part = dmsum.bed_lines(chrom, strand, self.mo['Base'], touch, cov, mod, first_pos=first)
-                parts[key] = len(part)
                 if write:
+                    parts[key] = 0
                     with open(out_path(chrom, strand) + '.part%d' % self.rank, 'wb') as fh:
-                        fh.write(part)
+                        for part in dmsum.bed_parts(chrom, strand, self.mo['Base'], touch, cov, mod, first_pos=first):
+                            fh.write(part)
+                            parts[key] += len(part)
                 else:
+                    part = dmsum.bed_lines(chrom, strand, self.mo['Base'], touch, cov, mod, first_pos=first)
+                    parts[key] = len(part)
                     beds[(chrom, strand)] = part        # (tests: the caller joins the ranks' parts itself)
-                self.stats['bed_bytes'] += len(part)
+                self.stats['bed_bytes'] += parts[key]
             else:
                 if self.world > 1:
                     s.sync()

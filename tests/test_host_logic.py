@@ -268,3 +268,26 @@ def test_stored_chunks_equal_the_per_read_tables(tmp_path):
             for k in range(3):
                 np.add.at(got[k], p, (fl >> k) & 1)
         assert np.array_equal(got, want) and want[0].sum() > 0
+
+
+def test_bed_parts_join_to_bed_lines():
+    """summary.bed_parts (slices of the table formatted by several threads, in position order) joined = summary.bed_lines = the
+    line-by-line restatement of the reference's writer - also for a slice that starts at a later position (a rank's share)."""
+    from deepmod_amd import _lib, summary
+    try:
+        _lib.load()
+    except _lib.DeepModHipError:
+        pytest.skip("library not built")
+    rng = np.random.default_rng(8)
+    n = 50000
+    touch = ((rng.random(n) < 0.3) * rng.integers(1, 4, n)).astype(np.int32)
+    touch[12000:30000] = 0                                   # slices without a line
+    cov = rng.integers(0, 1500, n).astype(np.int32)
+    mod = np.minimum(cov, rng.integers(0, 1500, n)).astype(np.int32)
+    whole = summary.bed_lines('chrQ', '-', 'C', touch, cov, mod)
+    assert whole == summary.bed_lines_py('chrQ', '-', 'C', touch, cov, mod)
+    for sl, th in ((4096, 8), (7777, 3), (1 << 22, 8), (50000, 1)):
+        assert b''.join(p.tobytes() for p in summary.bed_parts('chrQ', '-', 'C', touch, cov, mod, slice_positions=sl, threads=th)) == whole
+    shifted = summary.bed_lines('chrQ', '-', 'C', touch, cov, mod, first_pos=10 ** 9)
+    assert b''.join(p.tobytes() for p in summary.bed_parts('chrQ', '-', 'C', touch, cov, mod, first_pos=10 ** 9, slice_positions=999, threads=4)) == shifted
+    assert list(summary.bed_parts('chrQ', '+', 'C', np.zeros(100, np.int32), cov[:100], mod[:100])) == []

@@ -7,8 +7,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from deepmod_amd import synth, synth_reads
 
-GENOME_LEN = 4_641_652
-CHROM = "NC_000913.3"
+GENOME_LEN = int(os.environ.get("DM_E2E_GENOME", 4_641_652))      # DM_E2E_GENOME=248956422: a chr1-sized contig (BASELINE configs[3], one rank's view)
+CHROM = "NC_000913.3" if GENOME_LEN == 4_641_652 else "chr1"
 READS_PER_FILE = 100
 
 

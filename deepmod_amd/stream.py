@@ -1275,9 +1275,12 @@ class WorkList:
         self._items = list(items)
         self.n = len(self._items)
         self.head = ctx.Value('q', 0)
-        if directory is None and os.path.isdir('/dev/shm'):
+        if directory is None and os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK):
             directory = '/dev/shm'
-        fd, self.path = tempfile.mkstemp(prefix='deepmod_work_', suffix='.pkl', dir=directory)
+        try:
+            fd, self.path = tempfile.mkstemp(prefix='deepmod_work_', suffix='.pkl', dir=directory)
+        except OSError:                      # (a full or read-only /dev/shm: the default temporary directory)
+            fd, self.path = tempfile.mkstemp(prefix='deepmod_work_', suffix='.pkl')
         with os.fdopen(fd, 'wb') as fh:
             pickle.dump(self._items, fh, protocol=4)
 

@@ -451,16 +451,19 @@ def stored_chunks(moptions, sp_options, cur_chr, cur_strand, base, readers: int 
               | ((st['mod_pred'][rows] == 1).astype(np.uint8) << 2))
         return (st['refbasei'][rows].astype(np.int64), fl)
 
+    stores = list(by_store)
+    ahead = 2 * max(1, readers)             # stores in flight: the readers never run further ahead of the consumer than this
     with ThreadPoolExecutor(max(1, readers)) as pool:
-        for out in pool.map(one, list(by_store)):
-            if isinstance(out, list):
-                for m_pred, mapped_chrom, mapped_strand in out:
-                    if not (mapped_chrom == cur_chr and mapped_strand == cur_strand):
-                        print("ERRoR not the same chr (real=%s vs expect=%s) and strand (real=%s VS expect=%s)" %
-                              (mapped_chrom, cur_chr, mapped_strand, cur_strand))
-                    yield m_pred
-            else:
-                yield out
+        for g in range(0, len(stores), ahead):
+            for out in pool.map(one, stores[g:g + ahead]):
+                if isinstance(out, list):
+                    for m_pred, mapped_chrom, mapped_strand in out:
+                        if not (mapped_chrom == cur_chr and mapped_strand == cur_strand):
+                            print("ERRoR not the same chr (real=%s vs expect=%s) and strand (real=%s VS expect=%s)" %
+                                  (mapped_chrom, cur_chr, mapped_strand, cur_strand))
+                        yield m_pred
+                else:
+                    yield out
 
 
 def sum_handler(moptions, chr_strand_Q, device=0):
@@ -738,17 +741,16 @@ def mDetect_manager(moptions):
         if streamed:
             # a streaming run writes nothing per batch: the batch is only the unit the feeders take from the work queue, and the
             # counters are sums, so the BED does not depend on it. The reference's default (1000 single-read FAST5 files) would put
-            # a whole run of multi-read containers into ONE batch and leave all feeders but one idle: keep >= 8 batches per feeder
+            # a whole run of multi-read containers into ONE batch and leave all feeders but one idle: keep >= 8 batches per feeder,
+            # and cut them to fit the hand-over slots (feature rows are no larger than the containers they come from: a batch of
+            # <= 0.8 slot of input fits its slot)
             per_batch = max(1, min(per_batch, -(-len(files) // (8 * moptions['threads']))))
-        if streamed:       # (feature rows are no larger than the containers they come from: a batch of <= 0.8 slot of input fits its slot)
             items = plan_batches_sized(files, per_batch, int(0.8 * (int(moptions.get('feeder_slot_mb', 128)) << 20)))
-        else:
-            items = plan_batches(files, per_batch)
-        if streamed:
             _BASE_OF_RUN[0] = moptions['Base']
             ledger, stats = _run_streaming_detect(moptions, ctx, pmanager, items, ngpu)
             _print_stream_stats(stats, time.time() - t0, time.time() - moptions['_t_manager'])
         else:
+            items = plan_batches(files, per_batch)
             ledger = _run_stored_detect(moptions, ctx, pmanager, items, ngpu)
             moptions['predpath'] = moptions['outFolder'] + '/' + moptions['FileID']
         _report_errors(ledger)

@@ -384,6 +384,7 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                         lib.dm_rows_add_packed(h, n, len(arrs[3]), n_tab, len(arrs[7]), len(contigs), *[a.ctypes.data for a in arrs]) != 0):
                     # offset tables that do not fit their arrays (a truncated / damaged container): the file is reported, the batch goes on
                     out.errors["Cannot open container"].append(cf)
+                    print("Cannot open container: %s (%s)" % (cf, _lib.last_error() or 'offset tables of the wrong length'))
                     continue
                 srcs.extend([cf] * n)
             for c, ln in pk.get('contig_len', {}).items():

@@ -282,6 +282,8 @@ def main():
     if lib.dm_device_count() < 1:
         raise SystemExit("bench.py: no gfx950 device visible; there is no CPU fallback")
     device = local_rank if dist_mode else 0
+    if os.environ.get("DM_BENCH_ONE_DEVICE") == "1":      # test hook: every rank on device 0 (two real processes on a one-GPU box; RCCL refuses
+        device = 0                                        # duplicate devices, so this exercises the rendezvous and the no-RCCL control plane)
 
     communicator = rdv = control = comm_error = None
     if dist_mode:
@@ -422,7 +424,7 @@ def main():
             "config": {"workload": "configs[1]: rnn_conmodC_P100wd21_f7ne1u0_4 geometry (3x100 BiLSTM, wd21, f7), "
                                    "synthetic weights (real .data shards absent), %d windows/step resident in HBM, "
                                    "%d distinct batches (1,048,576 windows)" % (BATCH, n_batches),
-                       "batch": BATCH, "windows_total": total_windows, "parallelism": "window-sharded x%d" % world, "forced_dist_dry_run": bool(dist_mode and world == 1), "setup_launches": SETUP_LAUNCHES,
+                       "batch": BATCH, "windows_total": total_windows, "parallelism": "window-sharded x%d" % world, "forced_dist_dry_run": bool(dist_mode and world == 1), "all_ranks_on_device_0_test_hook": os.environ.get("DM_BENCH_ONE_DEVICE") == "1", "setup_launches": SETUP_LAUNCHES,
                        "precision": P["label"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": P["peak"], "unit": "TFLOP/s",
                          "frac": achieved / P["peak"], "traffic": (traffic or {}).get("bytes"),
@@ -444,7 +446,7 @@ def main():
         elif control is not None:
             out["multi_gpu"] = {"collective": "NOT RUN: RCCL could not be set up, the final merge of the counters was skipped (barriers and the "
                                               "max over ranks went through the rendezvous files); the data path has no collective, so `value` stands",
-                                "rccl_error": comm_error, "per_rank": per_rank, "measured_on_hardware_with_more_than_one_rank": bool(world > 1)}
+                                "rccl_error": comm_error, "per_rank": per_rank, "measured_on_hardware_with_more_than_one_rank": bool(world > 1 and os.environ.get("DM_BENCH_ONE_DEVICE") != "1")}
         if world == 1 and not args.no_extras:
             out["extras"] = extras(m, _lib, model, args.precision, x_dev[0], x0, prob_dev, cls_dev)
         if world == 1 and not args.no_cpu_baseline:

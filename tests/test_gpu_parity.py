@@ -383,6 +383,33 @@ def test_bench_keeps_its_line_when_rccl_cannot_be_set_up(gpu_device):
     assert len(mg["per_rank"]) == 1 and mg["per_rank"][0]["slice_sums"][0] == out["summary_check"]["touch"]
 
 
+def test_bench_two_processes_on_one_gpu(gpu_device):
+    """The driver's N > 1 launch with two REAL processes on this one-GPU box (DM_BENCH_ONE_DEVICE=1 puts both ranks on device 0):
+    torch.distributed.run as the launcher, the file rendezvous between two processes, the RCCL id from rank 0 to rank 1.  RCCL refuses
+    two ranks on one device (ncclCommInitRank: invalid usage) - on both ranks, which then agree to go on without it: barriers and the
+    max over ranks through the rendezvous files, one JSON line from rank 0 with both ranks' rates."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, DM_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29535", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["all_ranks_on_device_0_test_hook"] is True and out["scaling"] == "weak"
+    mg = out["multi_gpu"]
+    assert mg["collective"].startswith("NOT RUN") and "ncclCommInitRank" in mg["rccl_error"]
+    assert [r["rank"] for r in mg["per_rank"]] == [0, 1] and all(r["windows_per_s"] > 1e6 for r in mg["per_rank"])
+    assert out["config"]["windows_total"] == 2 * 4 * 65536
+    assert out["summary_check"]["touch"] == sum(r["slice_sums"][0] for r in mg["per_rank"]) > 0
+    assert mg["measured_on_hardware_with_more_than_one_rank"] is False
+
+
 def test_batched_reads_equal_per_read_calls(models, tmp_path, gpu_device):
     """mPredict_batch (one device call for many reads, concatenated feature matrices) must give exactly
     what the reference-granularity mPredict1 gives read by read."""

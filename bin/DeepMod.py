@@ -101,6 +101,8 @@ def mDetect(args):
     if ngpu < 1:
         raise SystemExit('Error: no gfx950 GPU visible (this build has no CPU path)')
     mo['gpus'] = min(args.gpus, ngpu) if args.gpus else ngpu
+    if os.environ.get('DEEPMOD_ONE_DEVICE') == '1' and args.gpus:      # test hook: --gpus N processes, all on device 0 (a one-GPU box; RCCL
+        mo['gpus'], mo['one_device'] = args.gpus, True                  # refuses duplicate devices: this exercises start-up, rendezvous and the abort path)
     detect.mDetect_manager(mo)
 
 

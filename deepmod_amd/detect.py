@@ -640,7 +640,8 @@ def _run_streaming_detect(moptions, ctx, pmanager, items, ngpu):
 
     try:
         _run_processes(ctx, stream.stream_rank_main,
-                       [(run_opts, r, world, r, work_q, result_q, feeders, feeder_procs) for r in range(world)], 'streaming detect', collect)
+                       [(run_opts, r, world, 0 if moptions.get('one_device') else r, work_q, result_q, feeders, feeder_procs) for r in range(world)],
+                       'streaming detect', collect)
     finally:
         work_q.close()
     while collect():

@@ -161,3 +161,27 @@ def test_detect_cli_on_raw_containers_matches_oracle_pipeline(tmp_path, gpu_devi
         got = open('%s/raw1/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read()
         assert got == want
         assert len(got) > 500
+
+
+def test_two_rank_run_that_cannot_build_its_communicator_fails_fast_and_clean(tmp_path, gpu_device):
+    """`--gpus 2` with both GPU processes on device 0 (DEEPMOD_ONE_DEVICE=1, a test hook for one-GPU boxes): two real ranks and their
+    feeders start, meet at the file rendezvous, and RCCL refuses the communicator (two ranks on one device).  The product has no merge
+    without RCCL: the run must end within seconds with a non-zero exit code and the RCCL error in its output - not hang in a
+    collective, not write a BED or the .done marker, not leave hand-over files in /dev/shm."""
+    import time
+    wrk = tmp_path / 'reads'
+    synth_reads.write_synthetic_run(str(wrk), n_reads=24, reads_per_file=3, genome_len=20000, seed=3, chrom='chrA', min_len=300, max_len=900)
+    prefix = str(tmp_path / 'model' / 'm')
+    os.makedirs(os.path.dirname(prefix))
+    synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)
+    out = str(tmp_path / 'out')
+    before = set(os.listdir('/dev/shm')) if os.path.isdir('/dev/shm') else set()
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bin', 'DeepMod.py'), 'detect', '--wrkBase', str(wrk), '--modfile', prefix, '--outFolder', out,
+                          '--FileID', 'two', '--threads', '4', '--Base', 'C', '--gpus', '2'], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, DEEPMOD_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert res.returncode != 0 and time.time() - t0 < 120
+    assert 'ncclCommInitRank' in res.stderr and 'a streaming detect worker died' in res.stderr
+    assert not os.path.exists(out + '/two.done') and not glob.glob(out + '/two/*.bed')
+    if os.path.isdir('/dev/shm'):
+        assert not [f for f in set(os.listdir('/dev/shm')) - before if f.startswith('deepmod')]

@@ -1195,7 +1195,7 @@ class StreamEngine:
             for key in keys:
                 chrom, strand = key.split("\t")
                 self.summaries[(chrom, strand)].grow(max(self.summaries[(chrom, strand)].length, lens.get(chrom, 0)))
-            with ThreadPoolExecutor(min(4, len(keys))) as pool:
+            with ThreadPoolExecutor(min(8, len(keys))) as pool:
                 for key, bed in zip(keys, pool.map(fetch_format_write, keys)):
                     beds[tuple(key.split("\t"))] = bed
             keys = []

@@ -671,8 +671,8 @@ def signal_server(requests, answers, device: int, stats=None):
     writes its results there, and they go back into the request file."""
     import mmap
     from . import _lib, model as dm, signal as dmsignal
-    norm = dmsignal.SignalNormalizer(device)
-    lib = norm._lib
+    norm = None           # its dm_signal handle is made for the first request: a run of feature containers never needs one, and
+    lib = _lib.load()     # a raw run's first request arrives after the model is on the device (no three-way race for the HIP start-up)
     maps = {}
     pinned = None
     try:
@@ -683,6 +683,8 @@ def signal_server(requests, answers, device: int, stats=None):
             wid, path, size, n, n_raw, n_ev = req
             t0 = time.perf_counter()
             try:
+                if norm is None:
+                    norm = dmsignal.SignalNormalizer(device)
                 if maps.get(wid, (None, 0))[1] != size:
                     if wid in maps:
                         maps[wid][0].close()
@@ -720,7 +722,8 @@ def signal_server(requests, answers, device: int, stats=None):
             mm.close()
         if pinned is not None:
             pinned.free()
-        norm.close()
+        if norm is not None:
+            norm.close()
 
 
 

@@ -216,6 +216,59 @@ def fuzz_events_and_raw(lib, rng, iters):
     return counts
 
 
+def fuzz_mapped(lib, rng, iters):
+    """dm_rows_add_mapped: the caller's own alignment tables and event tables, good and damaged."""
+    counts = {'refused': 0, 'accepted': 0}
+    for it in range(iters):
+        n = int(rng.integers(1, 5))
+        ntab = rng.integers(80, 500, n)
+        bmi_off = np.concatenate([[0], np.cumsum(ntab)]).astype(np.int64)
+        T = int(bmi_off[-1])
+        refb = rng.choice(list(b'ACGT-N'), T).astype(np.uint8).view('S1')
+        readb = rng.choice(list(b'ACGT-'), T, p=[.24, .24, .24, .24, .04]).astype(np.uint8).view('S1')
+        refi = np.sort(rng.integers(0, 100000, T)).astype(np.int64)
+        nev = np.array([int((readb[bmi_off[r]:bmi_off[r + 1]] != b'-').sum()) + int(rng.integers(0, 30)) for r in range(n)])
+        mev_off = np.concatenate([[0], np.cumsum(nev)]).astype(np.int64)
+        E = int(mev_off[-1])
+        m_mean, m_stdv = rng.normal(0, 1, E).astype(np.float32), np.abs(rng.normal(0.3, 0.1, E)).astype(np.float32)
+        m_len = rng.integers(1, 30, E).astype(np.uint64)
+        m_base = rng.choice(list(b'ACGT'), E).astype(np.uint8).view('S1')
+        sc, ec = rng.integers(0, 10, n).astype(np.int64), rng.integers(0, 10, n).astype(np.int64)
+        contig, strand = np.zeros(n, np.int32), rng.integers(0, 2, n).astype(np.int32)
+        fe = np.full(n, -1, np.int64)
+        n_tab, n_ev, n_contigs = T, E, 1
+        kind = int(rng.integers(0, 9))
+        if kind == 0:
+            bmi_off[int(rng.integers(0, n + 1))] = int(rng.integers(-20, T + 900))
+        elif kind == 1:
+            mev_off[int(rng.integers(0, n + 1))] = int(rng.integers(-20, E + 900))
+        elif kind == 2:
+            n_tab = int(rng.integers(0, T))
+            refb, readb, refi = refb[:n_tab].copy(), readb[:n_tab].copy(), refi[:n_tab].copy()
+        elif kind == 3:
+            n_ev = int(rng.integers(0, E))
+            m_mean, m_stdv, m_len, m_base = m_mean[:n_ev].copy(), m_stdv[:n_ev].copy(), m_len[:n_ev].copy(), m_base[:n_ev].copy()
+        elif kind == 4:
+            sc[int(rng.integers(0, n))] = int(rng.choice([-3, 10 ** 12, 2 ** 62]))
+        elif kind == 5:
+            contig[int(rng.integers(0, n))] = int(rng.choice([-1, 1, 2 ** 30]))
+        elif kind == 6:
+            strand[int(rng.integers(0, n))] = int(rng.choice([-1, 2]))
+        elif kind == 7:
+            fe[:] = rng.choice([-7, 0, 3, 499, 501, 10 ** 9], n)
+        h = lib.dm_rows_create(b'C')
+        with_stats = bool(it & 1)
+        rc = lib.dm_rows_add_mapped(h, n, n_tab, n_ev, n_contigs, p(bmi_off), p(refb), p(readb), p(refi), p(sc), p(ec), p(contig), p(strand), p(mev_off), p(m_mean),
+                                    p(m_stdv), p(m_len), p(m_base), p(m_mean) if with_stats else None, p(m_stdv) if with_stats else None, p(fe) if with_stats else None)
+        if rc == 0:
+            assert drain(lib, h, n_contigs, compact=bool(it & 2)) >= 0, _lib.last_error()
+            counts['accepted'] += 1
+        else:
+            counts['refused'] += 1
+        lib.dm_rows_destroy(h)
+    return counts
+
+
 def fuzz_bed(lib, rng, iters):
     for _ in range(iters):
         n = int(rng.integers(0, 400))
@@ -257,6 +310,7 @@ if __name__ == '__main__':
     print('damaged feature containers:', fuzz_packed(lib, files, rng, iters))
     print('alignment walk:', fuzz_map_read(lib, rng, 4 * iters))
     print('event tables and alignment records:', fuzz_events_and_raw(lib, rng, iters))
+    print('caller-supplied alignment tables:', fuzz_mapped(lib, rng, iters))
     fuzz_bed(lib, rng, iters // 3)
     print('BED formatter: ok')
     print('FUZZ-OK')

@@ -229,8 +229,41 @@ Packed16 pack_weights_f16(const float* flat) {
 // count of the int32 accumulator is i8s = sw 2^-12 / 127^2 pre-activation units for both slots.  Layer 0's mixed k16-step
 // (t = 6: own units 96..99, bias slot, RAW features) keeps its f16 lo record: the kernel runs it with three f16 products.
 // (An int32 accumulator cannot overflow: 2 * 208 slots * 127 * 127 < 2^23.)
+#ifndef DM_WLO_TRUNC_DEFAULT
+#define DM_WLO_TRUNC_DEFAULT 0
+#endif
+#include <cstdlib>
+// lo half of a weight with its low m mantissa bits rounded away (round to nearest even on the bit pattern; m = 0: unchanged)
+static inline _Float16 round_lo_bits(_Float16 lo, int m) {
+    if (m <= 0) return lo;
+    unsigned short b;
+    std::memcpy(&b, &lo, 2);
+    const unsigned short sign = b & 0x8000u;
+    unsigned mag = b & 0x7FFFu;
+    const unsigned half = 1u << (m - 1), lsb = (mag >> m) & 1u;
+    mag = (mag + half - 1u + lsb) & ~((1u << m) - 1u);      // a carry into the exponent is the right value (next binade)
+    if (mag >= 0x7C00u) mag = 0x7BFFu & ~((1u << m) - 1u);
+    b = (unsigned short)(sign | mag);
+    std::memcpy(&lo, &b, 2);
+    return lo;
+}
+// The operand-toggle dial of round 4 (profiles/r04/lo_trunc_dial.txt: closed, not adopted - already m = 3 leaves the 3e-5 bar for a
+// change of arithmetic and returns < 1.5 %).  The product packs full lo halves; only an experiment build (-DDM_WLO_TRUNC_ENV,
+// tools/lo_trunc_dial.py) reads the knob from the environment.
+static int wlo_trunc_bits() {
+#ifdef DM_WLO_TRUNC_ENV
+    const char* e = std::getenv("DM_WLO_TRUNC");
+    if (e && *e) {
+        const int m = std::atoi(e);
+        return m < 0 ? 0 : (m > 9 ? 9 : m);
+    }
+#endif
+    return DM_WLO_TRUNC_DEFAULT;
+}
+
 Packed16 pack_weights_tile(const float* flat, const bool int8 = false, float* i8s = nullptr) {
     using namespace lstm16s;
+    const int wlo_m = int8 ? 0 : wlo_trunc_bits();
     Packed16 P;
     P.w.assign(WEIGHT_BYTES, 0);
     P.len_shift = choose_len_shift(flat);
@@ -322,7 +355,7 @@ Packed16 pack_weights_tile(const float* flat, const bool int8 = false, float* i8
                             const _Float16 hi = (_Float16)v;
                             const _Float16 lo = (_Float16)(v - (float)hi);
                             dst[(0 * 64 + lane) * 8 + j] = hi;
-                            if (!rec8) dst[(1 * 64 + lane) * 8 + j] = lo;
+                            if (!rec8) dst[(1 * 64 + lane) * 8 + j] = round_lo_bits(lo, wlo_m);
                             else {
                                 const float s8 = 127.0f / sw[gate];
                                 const float qh = std::nearbyint((float)hi * s8), ql = std::nearbyint((float)lo * s8 * 4096.0f);

@@ -549,7 +549,9 @@ def _run_processes(ctx, target, argsets, what, poll=None):
                     p.terminate()
             break
         if poll is None or not poll():
-            multiprocessing.connection.wait([p.sentinel for p in procs], timeout=0.02)      # returns the moment one of them ends
+            # returns the moment one of the RUNNING ones ends (the sentinel of a process that has exited stays ready: waiting on it
+            # too would turn this loop into a busy spin for the tail of the run)
+            multiprocessing.connection.wait([p.sentinel for p in procs if p.is_alive()] or [], timeout=0.02)
     for p in procs:
         p.join()
     if any(p.exitcode != 0 for p in procs):

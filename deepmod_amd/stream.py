@@ -275,7 +275,7 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                         rid = None
                     ids.append(rid)
                     id_src.append(f5f)
-                raw_parts.append(z['raw'])
+                raw_parts.append(z['raw'][:int(ro[-1])])          # samples behind the last read's end would shift every later container's offsets
                 raw_offs.extend((raw_offs[-1] + ro[1:]).tolist())
                 ev_offs.extend((ev_offs[-1] + mev_off[1:]).tolist())
                 cols['mean'].append(m_mean[:got]); cols['stdv'].append(m_stdv[:got]); cols['start'].append(m_start[:got])
@@ -342,6 +342,8 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                     any_all = any(mr[0] in ['', None] and mr[1] in ['', None] and mr[2] in ['', None] for mr in region)
                     if any_all:
                         region = []
+                    elif not region:
+                        skip[:] = 1          # an EMPTY region list matches nothing (myDetect.py:548-556 leaves isinreg False): n_region = 0 below means "no filter"
                     rg_c = np.array([(-1 if mr[0] in ['', None] else contigs.get(mr[0], 0x7fffffff)) for mr in region] or [0], np.int32)   # a contig no record of the batch names: matches nothing
                     rg_lo = np.array([(-1 if mr[1] in ['', None] else int(mr[1])) for mr in region] or [0], np.int64)
                     rg_hi = np.array([(-1 if mr[2] in ['', None] else int(mr[2])) for mr in region] or [0], np.int64)
@@ -956,6 +958,11 @@ class HipBackend:
         self.sess.close()
 
 
+def finalize_threads(n_tables: int, longest: int, budget_positions: int = 250_000_000) -> int:
+    """Tables fetched and formatted side by side by a single rank's finalize: bounded by the positions in flight."""
+    return max(1, min(8, n_tables, budget_positions // max(int(longest), 1)))
+
+
 class StreamEngine:
     """Rank-local streaming detect: pulls worker batches, keeps per contig x strand counters, merges at the end."""
 
@@ -1180,17 +1187,17 @@ class StreamEngine:
             touch, cov, mod = s.fetch()
             s.close()
             if not write:
-                return dmsum.bed_lines(chrom, strand, self.mo['Base'], touch, cov, mod)
+                return dmsum.bed_lines(chrom, strand, self.mo['Base'], touch, cov, mod), 0
             # slices of the table formatted side by side and written in order; the text of a large contig is never held whole
-            fh = None
+            fh, nbytes = None, 0
             for part in dmsum.bed_parts(chrom, strand, self.mo['Base'], touch, cov, mod):
                 if fh is None:                      # the reference writes no file for an empty table (myDetect.py:1109)
                     fh = open(out_path(chrom, strand), 'wb')
                 fh.write(part)
-                self.stats['bed_bytes'] += len(part)
+                nbytes += len(part)                 # (summed by the caller: several of these run side by side)
             if fh is not None:
                 fh.close()
-            return b'' if fh is None else None      # None: written to its file
+            return (b'' if fh is None else None), nbytes      # None: written to its file
 
         if not scattered and self.world == 1 and len(keys) >= 1:
             # a single rank: the tables are independent (own counters, own stream, own file) - contig x strand tables side by side
@@ -1198,9 +1205,13 @@ class StreamEngine:
             for key in keys:
                 chrom, strand = key.split("\t")
                 self.summaries[(chrom, strand)].grow(max(self.summaries[(chrom, strand)].length, lens.get(chrom, 0)))
-            with ThreadPoolExecutor(min(8, len(keys))) as pool:
-                for key, bed in zip(keys, pool.map(fetch_format_write, keys)):
+            # a table in flight holds 3 x length int32 on the host plus its text: at most ~2.5e8 positions (3 GB of counters) at a time,
+            # i.e. eight E. coli-sized tables side by side but one chr1-sized table after the other
+            longest = max(self.summaries[tuple(key.split("\t"))].length for key in keys)
+            with ThreadPoolExecutor(finalize_threads(len(keys), longest)) as pool:
+                for key, (bed, nbytes) in zip(keys, pool.map(fetch_format_write, keys)):
                     beds[tuple(key.split("\t"))] = bed
+                    self.stats['bed_bytes'] += nbytes
             keys = []
         for key in keys:
             chrom, strand = key.split("\t")

@@ -85,7 +85,10 @@ def fuzz_packed(lib, files, rng, iters):
                 a[k] = a[k][:int(rng.integers(0, len(a[k])))].copy()
             elif kind == 3:
                 k = ('start_clip', 'end_clip')[int(rng.integers(0, 2))]
-                a[k][int(rng.integers(0, n))] = int(rng.choice([-1, -10 ** 9, 10 ** 9, 2 ** 62, 0, 7]))
+                a[k][int(rng.integers(0, n))] = int(rng.choice([-1, -10 ** 9, 10 ** 9, 2 ** 62, 0, 7, 2 ** 63 - 1, -2 ** 63]))
+                if rng.integers(0, 4) == 0:                  # both clips at the ends of int64: n_events - start - end wraps into a small number
+                    i = int(rng.integers(0, n))
+                    a['start_clip'][i] = a['end_clip'][i] = int(rng.choice([2 ** 63 - 1, -2 ** 63, 2 ** 62]))
             elif kind == 4:
                 a['contig'][int(rng.integers(0, n))] = int(rng.choice([-1, 1, 5, 2 ** 30]))
             elif kind == 5:
@@ -249,7 +252,10 @@ def fuzz_mapped(lib, rng, iters):
             n_ev = int(rng.integers(0, E))
             m_mean, m_stdv, m_len, m_base = m_mean[:n_ev].copy(), m_stdv[:n_ev].copy(), m_len[:n_ev].copy(), m_base[:n_ev].copy()
         elif kind == 4:
-            sc[int(rng.integers(0, n))] = int(rng.choice([-3, 10 ** 12, 2 ** 62]))
+            i = int(rng.integers(0, n))
+            sc[i] = int(rng.choice([-3, 10 ** 12, 2 ** 62, 2 ** 63 - 1, -2 ** 63]))
+            if rng.integers(0, 2) == 0:
+                ec[i] = sc[i]                                # INT64_MAX twice: the subtraction wraps to n_events + 2
         elif kind == 5:
             contig[int(rng.integers(0, n))] = int(rng.choice([-1, 1, 2 ** 30]))
         elif kind == 6:

@@ -363,3 +363,29 @@ def test_damaged_feature_container_is_reported_and_the_batch_goes_on(tmp_path):
         assert got.n_reads == want.n_reads and got.n_rows == want.n_rows and got.groups == want.groups, damage
         assert np.array_equal(got.rows, want.rows) and np.array_equal(got.pos, want.pos) and np.array_equal(got.flags, want.flags), damage
         os.remove(bad)
+
+
+def test_clips_at_the_ends_of_int64_are_a_ledger_line_not_a_wild_read(tmp_path):
+    """Clip values near INT64_MAX / INT64_MIN in a container's metadata: `n_events - start_clip - end_clip` wraps to a
+    plausible count, so the clips are checked before any arithmetic with them - the read becomes an index error of the ledger, the other
+    reads of the container and the batch go on, nothing is read outside the event column."""
+    from deepmod_amd import npzmap, predstore
+    files = synth_reads.write_synthetic_run(str(tmp_path / 'in'), n_reads=6, reads_per_file=3, genome_len=8000, seed=5, chrom='chrA',
+                                            min_len=200, max_len=600)
+    mo = {'Base': 'C', 'outFolder': str(tmp_path / 'out'), 'fnum': 7, 'hidden': 100, 'windowsize': 21}
+    os.makedirs(mo['outFolder'])
+    want = stream._prepare_batch_c(dict(mo), [files[0]])
+    for clips in ((2 ** 63 - 1, 2 ** 63 - 1), (-2 ** 63, -2 ** 63), (2 ** 63 - 1, 0), (0, 2 ** 62), (2 ** 62, 2 ** 62)):
+        pk = predstore.load_packed(files[1])
+        z = {k: np.array(pk[k]) for k in ('tx', 'refbase', 'readbase', 'refbasei', 'evbase', 'row_off', 'bmi_off', 'ev_off')}
+        reads = [dict(r) for r in pk['reads']]
+        reads[1]['start_clip'], reads[1]['end_clip'] = clips
+        z['format'] = np.array(2)
+        z['meta'] = np.array(json.dumps({'reads': reads, 'contig_len': {}}))
+        bad = str(tmp_path / 'in' / ('clips' + predstore.CONTAINER_SUFFIX))
+        with open(bad, 'wb') as fh:
+            npzmap.savez_aligned(fh, **z)
+        got = stream._prepare_batch_c(dict(mo), [files[0], bad])
+        assert got.n_reads == want.n_reads + 2, (clips, got.n_reads, dict(got.errors))
+        assert sum(len(v) for v in got.errors.values()) >= 1, clips
+        os.remove(bad)

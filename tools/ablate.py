@@ -34,6 +34,9 @@ VARIANTS = {
     "s_ad2": ["-DDM16S_ADIST=2"], "s_ad4": ["-DDM16S_ADIST=4"], "s_ad5": ["-DDM16S_ADIST=5"], "s_ad6": ["-DDM16S_ADIST=6"], "s_pre0": ["-DDM16S_PRE=0"], "s_pre1": ["-DDM16S_PRE=1"], "s_pre3": ["-DDM16S_PRE=3"], "s_pre4": ["-DDM16S_PRE=4"],
     "s_nocell_noldsa": ["-DDM16S_ABL_NOCELL", "-DDM16S_ABL_NOLDSA"],
     # (round 3's timing-only "int8 cross terms" variants s_i8t / s_i8t_nox became the real DM_PREC_F16I8: git show 8a84c8d:deepmod_amd/csrc/lstm_f16s.hip.inc)
+    # round 4: the operand-toggle dial (tools/lo_trunc_dial.py): packer knob from the environment + a_lo mask of m bits
+    "alo0": ["-DDM_WLO_TRUNC_ENV"], "alo3": ["-DDM_WLO_TRUNC_ENV", "-DDM16S_ALO_TRUNC=3"], "alo5": ["-DDM_WLO_TRUNC_ENV", "-DDM16S_ALO_TRUNC=5"],
+    "alo6": ["-DDM_WLO_TRUNC_ENV", "-DDM16S_ALO_TRUNC=6"],
     "trace": ["-DDM_TRACE"],                                   # f16x3 kernel: per-wave timeline of one stage
     "w4": ["-DDM16_WAVES=4", "-DDM16_MT=2"],                   # f16x3 kernel: 4 waves x 2 M-tiles (one wave per SIMD)
     "w4timing": ["-DDM16_WAVES=4", "-DDM16_MT=2", "-DDM_TIMING"],

@@ -19,15 +19,10 @@
 #include "head.hip.inc"
 #include "lstm_f32.hip.inc"
 #include "lstm_f16s.hip.inc"
-#ifdef DM_WITH_F16X3_LM   // the layer-major split-f16 kernel of round 1: an experiment build, not part of the product
-#include "../../tools/experiments/f16lm/lstm_f16lm.hip.inc"
+#ifdef DM_WITH_F16X3_ROLES   // the matrix / cell wave-pair form of the default kernel (round 4): an experiment build, not part of the product
+#include "../../tools/experiments/f16r/lstm_f16r.hip.inc"
 #endif
 
-#ifdef DM_TRACE2
-#define DM16_TRACE2_LDS 2048
-#else
-#define DM16_TRACE2_LDS 0
-#endif
 
 
 namespace {
@@ -158,62 +153,6 @@ int choose_len_shift(const float* flat) {
     return k;
 }
 
-#ifdef DM_WITH_F16X3_LM
-Packed16 pack_weights_f16(const float* flat) {
-    using namespace lstm16;
-    Packed16 P;
-    P.w.assign(size_t(2) * KS_DIR * KSTEP_BYTES, 0);
-    P.len_shift = choose_len_shift(flat);
-    const float len_mul = std::ldexp(1.0f, P.len_shift);
-    const float* p = flat;
-    for (int d = 0; d < 2; ++d) {
-        int ks_base = 0;
-        for (int l = 0; l < 3; ++l) {
-            const int kin = l == 0 ? NFEAT : HID;
-            const int nks = l == 0 ? KS_L0 : KS_L12;
-            const float* kern = p;
-            const float* bias = p + size_t(kin + HID) * 400;
-            p += size_t(kin + HID) * 400 + 400;
-            const int own_k0 = l == 0 ? 0 : 8 * KG_H;     // k index of own hidden unit 0; unit slot 100 carries the constant 1.0
-            for (int i = 0; i < nks; ++i) {
-                const int ks = l == 0 ? ks_at<true>(i) : ks_at<false>(i);     // stream position -> k-step
-                _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + size_t(d * KS_DIR + ks_base + i) * KSTEP_BYTES);
-                for (int t = 0; t < NT; ++t)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j) {
-                            const int k = 32 * ks + 8 * (lane >> 4) + j;
-                            int krow = -1;   // row of the TF kernel; -1 = zero padding
-                            float mul = 1.0f;
-                            if (l == 0) {
-                                if (k < HID) krow = NFEAT + k;                                  // own h
-                                else if (k >= 8 * KG_H && k < 8 * KG_H + NFEAT) krow = k - 8 * KG_H;   // x features
-                                else if (k == 8 * KG_H + NFEAT) {                               // slot 7: length row x 2^len_shift
-                                    krow = NFEAT - 1;
-                                    mul = len_mul;
-                                }
-                            } else {
-                                if (k < HID) krow = k;                                          // h of the layer below
-                                else if (k >= 8 * KG_H && k < 8 * KG_H + HID) krow = HID + (k - 8 * KG_H);   // own h
-                            }
-                            const int gc = gate_col(t, lane & 15);
-                            float v = krow < 0 ? 0.0f : kern[size_t(krow) * 400 + gc];
-                            if (k == own_k0 + HID) v = bias[gc] + ((gc >= 200 && gc < 300) ? 1.0f : 0.0f);   // bias row (+ forget_bias)
-                            v *= gate_scale(gc) * mul;
-                            if (!std::isfinite(v)) P.finite = false;
-                            else P.max_abs = std::max(P.max_abs, std::fabs(v));
-                            const _Float16 hi = (_Float16)v;
-                            const _Float16 lo = (_Float16)(v - (float)hi);
-                            dst[((size_t(t) * 2 + 0) * 64 + lane) * 8 + j] = hi;
-                            dst[((size_t(t) * 2 + 1) * 64 + lane) * 8 + j] = lo;
-                        }
-            }
-            ks_base += nks;
-        }
-    }
-    return P;
-}
-
-#endif  // DM_WITH_F16X3_LM
 
 // tile-major split-f16 packing (lstm_f16s.hip.inc): [dir][layer][tile][k16-step][hi|lo][lane][8 x f16].
 // A-operand lane l of record (tile T, k16-step t): gate row m = l % 32 -> unit 8T + m / 4, gate m % 4;
@@ -475,7 +414,6 @@ struct dm_model {
     float* d_wpack = nullptr;
     float* d_bpack = nullptr;
     float* d_hpack = nullptr;
-    unsigned char* d_wpack16 = nullptr;   // split-f16 weights in the layer-major kernel's layout (DM_PREC_F16X3_LM)
     unsigned char* d_wpack16s = nullptr;  // split-f16 weights in the tile-major layout (DM_PREC_F16X3)
     unsigned char* d_wpack16i = nullptr;  // the same layout with int8 cross-term records (DM_PREC_F16I8)
     float i8s[24] = {};                   // its fold scales [dir][layer][gate kind]
@@ -601,6 +539,10 @@ int ensure_f16s(dm_model* m) {
     HIP_TRY(hipMemcpy(m->d_wpack16s, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16s::bilstm_f16s_kernel<0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16s::LDS_BYTES)));
+#ifdef DM_WITH_F16X3_ROLES
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16r::bilstm_f16r_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16r::LDS_BYTES_R)));
+#endif
     return DM_OK;
 }
 
@@ -616,20 +558,6 @@ int ensure_f16i8(dm_model* m) {
     return DM_OK;
 }
 
-#ifdef DM_WITH_F16X3_LM
-int ensure_f16lm(dm_model* m) {
-    if (m->d_wpack16) return DM_OK;
-    int rc = ensure_f16_common(m);
-    if (rc) return rc;
-    Packed16 P = pack_weights_f16(m->host_weights.data());
-    HIP_TRY(hipMalloc(&m->d_wpack16, P.w.size()));
-    HIP_TRY(hipMemcpy(m->d_wpack16, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16::bilstm_f16x3_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16::LDS_BYTES) + DM16_TRACE2_LDS));
-    return DM_OK;
-}
-
-#endif
 
 // launch on device-resident buffers
 int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, float* d_prob, uint8_t* d_cls, const int* d_widx = nullptr) {
@@ -652,7 +580,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         ++m->events_used;
         HIP_TRY(hipEventRecord(e0, m->stream));
     }
-    if (m->precision == DM_PREC_F16X3 || m->precision == DM_PREC_F16I8) {
+    if (m->precision == DM_PREC_F16X3 || m->precision == DM_PREC_F16I8 || m->precision == DM_PREC_F16X3_ROLES) {
         using namespace lstm16s;
         const bool i8 = m->precision == DM_PREC_F16I8;
         int rc = i8 ? ensure_f16i8(m) : ensure_f16s(m);
@@ -676,47 +604,14 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         p.range_flag = m->d_range_flag + m->range_cur;
         const int grid = std::min(2 * p.ntiles, m->grid_cap);
         if (i8) hipLaunchKernelGGL(bilstm_f16s_kernel<1>, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
+#ifdef DM_WITH_F16X3_ROLES
+        else if (m->precision == DM_PREC_F16X3_ROLES) hipLaunchKernelGGL(lstm16r::bilstm_f16r_kernel, dim3(grid), dim3(lstm16r::THREADS_R), lstm16r::LDS_BYTES_R, m->stream, p);
+#endif
         else hipLaunchKernelGGL(bilstm_f16s_kernel<0>, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
         const long long npad = (long long)p.ntiles * TILE_M;
         hipLaunchKernelGGL(lstmhead::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
                            npad, m->bout[0], m->bout[1], d_prob, d_cls);
     } else
-#ifdef DM_WITH_F16X3_LM
-    if (m->precision == DM_PREC_F16X3_LM) {
-        using namespace lstm16;
-        int rc = ensure_f16lm(m);
-        if (rc) return rc;
-        Params p;
-        p.wpack = m->d_wpack16;
-        p.bpack = m->d_bpack;
-        p.hpack = m->d_wout;
-        p.bout0 = m->bout[0];
-        p.bout1 = m->bout[1];
-        p.x = d_x;
-        p.xstride = xstride;
-        p.n = n;
-        p.prob = d_prob;
-        p.cls = d_cls;
-        p.scratch = reinterpret_cast<unsigned char*>(m->d_scratch);
-        p.ntiles = int((n + TILE_M - 1) / TILE_M);
-        p.dbg = m->d_dbg;
-        p.dir_split = 1;      // work item = (tile, direction): half the latency of small batches, finer tail on large ones
-        if (p.dir_split) {
-            int rcp = ensure_plogit(m, p.ntiles);
-            if (rcp) return rcp;
-        }
-        p.plogit = m->d_plogit;
-        p.len_scale = std::ldexp(1.0f, -m->len_shift);
-        p.range_flag = m->d_range_flag + m->range_cur;
-        const int grid = std::min(p.dir_split ? 2 * p.ntiles : p.ntiles, m->grid_cap);
-        hipLaunchKernelGGL(bilstm_f16x3_kernel, dim3(grid), dim3(THREADS), LDS_BYTES + DM16_TRACE2_LDS, m->stream, p);
-        if (p.dir_split) {
-            const long long npad = (long long)p.ntiles * TILE_M;
-            hipLaunchKernelGGL(lstmhead::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
-                               npad, m->bout[0], m->bout[1], d_prob, d_cls);
-        }
-    } else
-#endif
     {
         using namespace lstm32;
         Params p;
@@ -890,9 +785,6 @@ int model_init(dm_model* m, const float* weights) {
     HIP_TRY(hipMemcpy(m->d_bpack, P.b.data(), P.b.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_hpack, P.h.data(), P.h.size() * sizeof(float), hipMemcpyHostToDevice));
     size_t scratch_bytes = size_t(m->grid_cap) * SCRATCH_FLOATS_PER_WG * sizeof(float);      // h sequences of the fp32 kernel
-#ifdef DM_WITH_F16X3_LM
-    scratch_bytes = std::max(scratch_bytes, size_t(m->grid_cap) * lstm16::SCRATCH_BYTES_PER_WG);
-#endif
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
     HIP_TRY(hipMemsetAsync(m->d_scratch, 0, scratch_bytes, m->stream));      // ordered with the launches of m->stream (non-blocking)
 #if defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2)
@@ -983,7 +875,6 @@ void dm_model_destroy(dm_model* m) {
     (void)hipFree(m->d_bpack);
     (void)hipFree(m->d_hpack);
     (void)hipFree(m->d_scratch);
-    (void)hipFree(m->d_wpack16);
     (void)hipFree(m->d_wpack16s);
     (void)hipFree(m->d_wpack16i);
     (void)hipFree(m->d_wout);
@@ -1015,11 +906,11 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
             m->grid_cap = m->num_cu - int(value);
             return DM_OK;
         case DM_OPT_PRECISION:
-            if (value != DM_PREC_F32 && value != DM_PREC_F16X3 && value != DM_PREC_F16X3_LM && value != DM_PREC_F16I8)
+            if (value != DM_PREC_F32 && value != DM_PREC_F16X3 && value != DM_PREC_F16X3_ROLES && value != DM_PREC_F16I8)
                 return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
-#ifndef DM_WITH_F16X3_LM
-            if (value == DM_PREC_F16X3_LM)
-                return fail(DM_EINVAL, "DM_PREC_F16X3_LM (the layer-major kernel of round 1) is not part of this build; rebuild with -DDM_WITH_F16X3_LM");
+#ifndef DM_WITH_F16X3_ROLES
+            if (value == DM_PREC_F16X3_ROLES)
+                return fail(DM_EINVAL, "DM_PREC_F16X3_ROLES (the wave-pair experiment kernel of round 4) is not part of this build; rebuild with -DDM_WITH_F16X3_ROLES");
 #endif
             if (value != DM_PREC_F32 && !m->f16_ok)
                 return fail(DM_EINVAL, "DM_PREC_F16X3 refused: a packed weight of this model is outside the f16 range (|w| x 2.886 > 65504)");
@@ -1060,7 +951,6 @@ int dm_predict_read_at(dm_model* m, const float* rows, int64_t m_rows, const int
     if (count == 0) return DM_OK;
     if (!rows || !centre) return fail(DM_EINVAL, "null input");
     if (m_rows < DM_WINDOW) return fail(DM_EINVAL, "%lld feature rows hold no window", (long long)m_rows);
-    if (m->precision == DM_PREC_F16X3_LM) return fail(DM_EINVAL, "dm_predict_read_at: not built into the layer-major experiment kernel");
     HIP_TRY(hipSetDevice(m->device));
     const bool rd = is_device_ptr(rows), cd = is_device_ptr(centre), pd = prob ? is_device_ptr(prob) : true, kd = cls ? is_device_ptr(cls) : true;
     if (rd && cd && pd && kd) {
@@ -1135,8 +1025,8 @@ int dm_model_get_info(dm_model* m, int key, int64_t* value) {
         case DM_INFO_F16_REPRESENTABLE: *value = m->f16_ok ? 1 : 0; return DM_OK;
         case DM_INFO_F16_LENGTH_SHIFT: *value = m->len_shift; return DM_OK;
         case DM_INFO_DEVICE: *value = m->device; return DM_OK;
-        case DM_INFO_HAS_F16X3_LM:
-#ifdef DM_WITH_F16X3_LM
+        case DM_INFO_HAS_F16X3_ROLES:
+#ifdef DM_WITH_F16X3_ROLES
             *value = 1;
 #else
             *value = 0;

@@ -116,7 +116,7 @@ def _ptr(a):
 class BiLSTMModel:
     """One dm_model on one GPU (one per process, like the reference's one TF session per process)."""
 
-    PRECISIONS = {"f32": _lib.DM_PREC_F32, "f16x3": _lib.DM_PREC_F16X3, "f16x3lm": _lib.DM_PREC_F16X3_LM, "f16i8": _lib.DM_PREC_F16I8}
+    PRECISIONS = {"f32": _lib.DM_PREC_F32, "f16x3": _lib.DM_PREC_F16X3, "f16x3r": _lib.DM_PREC_F16X3_ROLES, "f16i8": _lib.DM_PREC_F16I8}
 
     def __init__(self, tensors: Dict[str, np.ndarray], device: int = 0, precision: Optional[str] = None):
         self._lib = _lib.load()

@@ -74,10 +74,12 @@ extern "C" {
                                   beyond 65504 it is fed as x * 2^-k against a weight row stored x 2^k (exact rescale).
                                   An input outside these bounds (or NaN) makes the call fail with DM_ERANGE - synchronous
                                   calls on return, DM_OPT_ASYNC calls at the next dm_model_sync. */
-#define DM_PREC_F16X3_LM 2 /* the same arithmetic and range contract in the layer-major kernel of round 1
-                              (tools/experiments/f16lm: the h sequence of a layer goes through a per-workgroup global scratch);
-                              ~10 % slower.  Not part of the product build: selectable only in a library built with
-                              -DDM_WITH_F16X3_LM (DM_INFO_HAS_F16X3_LM), otherwise refused with DM_EINVAL. */
+#define DM_PREC_F16X3_ROLES 2 /* EXPERIMENT (round 4, tools/experiments/f16r): the arithmetic of DM_PREC_F16X3, bit for bit, with the work of a
+                              SIMD split between a matrix wave and a cell wave (two waves per SIMD, accumulators and h handed over
+                              through LDS): 6 % fewer cycles, the same time per launch - the part runs this path at its power limit and
+                              gives a saved cycle back as a lower clock (profiles/r04/README.md).  Not part of the product build:
+                              selectable only in a library built with -DDM_WITH_F16X3_ROLES (DM_INFO_HAS_F16X3_ROLES), otherwise
+                              refused with DM_EINVAL. */
 #define DM_PREC_F16I8 3    /* OPT-IN: the step-major kernel with hi*hi in f16 and BOTH cross terms of every product as one int8 MFMA
                               (v_mfma_i32_32x32x32_i8, int32 accumulation, folded into the fp32 pre-activations per tile): 2 issued
                               matrix units per product instead of 3, 10-12 % less time per window.  Operands carry ~19 bits instead
@@ -91,7 +93,7 @@ extern "C" {
 #define DM_INFO_F16_REPRESENTABLE 2  /* 1 if the weights fit DM_PREC_F16X3 */
 #define DM_INFO_F16_LENGTH_SHIFT 3   /* k above */
 #define DM_INFO_DEVICE 4
-#define DM_INFO_HAS_F16X3_LM 5       /* 1 if the library was built with the layer-major experiment kernel */
+#define DM_INFO_HAS_F16X3_ROLES 5    /* 1 if the library was built with the wave-pair experiment kernel */
 
 typedef struct dm_model dm_model;
 typedef struct dm_summary dm_summary;

@@ -30,3 +30,11 @@ def gpu_device(hip_lib):
     if n < 1:
         pytest.fail("GPU test selected but no gfx950 device is visible (no fallback path exists)")
     return 0
+
+
+def trained_like_weights():
+    """Weights with the statistics of a TRAINED BiLSTM (tests/golden/make_trained_like.py: the exact architecture trained with torch
+    autograd in the build container; the reference's own .data shards are absent): name -> float32 array, like synth.synthetic_weights."""
+    import numpy as np
+    z = np.load(os.path.join(GOLDEN, "trained_like_weights.npz"))
+    return {k.replace("|", "/"): np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}

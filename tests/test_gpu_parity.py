@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, trained_like_weights
 from deepmod_amd import model, synth
 from oracle import oracle_np
 
@@ -41,7 +41,7 @@ def models(gpu_device, request):
     def get(seed, scale):
         key = (seed, scale)
         if key not in cache:
-            w = synth.synthetic_weights(seed, scale)
+            w = trained_like_weights() if seed == "trained" else synth.synthetic_weights(seed, scale)
             m = model.BiLSTMModel(w, device=gpu_device)
             m.set_option(_lib.DM_OPT_PRECISION, prec)
             cache[key] = (w, m)
@@ -64,10 +64,30 @@ def test_golden_reference_graph(path, models):
     _check(prob, cls, g["prob"], g["cls"], models.tol)
 
 
+def test_trained_like_weights_reference_graph_and_oracle(models):
+    """Weights with TRAINED statistics (tests/golden/make_trained_like.py; kernel entries up to 1.7 beside a median of 0.05, saturated
+    gates, learnt biases - the reference's own .data shards are absent): the interpreted reference graph on the committed case, then the
+    oracle on 20,000 config-2 windows and on ragged sizes."""
+    w, m = models("trained", 0.0)
+    g = np.load(os.path.join(GOLDEN, "trained_like_case.npz"))
+    prob, cls = m.predict_windows(g["X"])
+    _check(prob, cls, g["prob"], g["cls"], models.tol)
+    for n, seed in ((20000, 31), (129, 32), (1, 33)):
+        x = synth.synthetic_windows(n, seed=seed)
+        prob, cls = m.predict_windows(x)
+        ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
+        err = _check(prob, cls, ref_prob, ref_cls, models.tol)
+        if n == 20000:
+            # where the kernels stand on trained statistics (profiles/r04/i8_tail.txt: worst window of 10^6): default / fp32 an order of
+            # magnitude inside the tolerance
+            assert err <= (3e-5 if models.precision != "f16i8" else models.tol), err
+            assert 0.02 < ref_cls.mean() < 0.98
+
+
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 127, 128, 129, 255, 1000, 4097])
-@pytest.mark.parametrize("scale", [1.0, 4.0])
+@pytest.mark.parametrize("scale", [1.0, 4.0, "trained"])
 def test_vs_oracle_ragged_sizes(n, scale, models):
-    w, m = models(21, scale)
+    w, m = models("trained" if scale == "trained" else 21, 0.0 if scale == "trained" else scale)
     x = synth.synthetic_windows(n, seed=100 + n)
     prob, cls = m.predict_windows(x)
     ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
@@ -317,21 +337,24 @@ def test_windows_picked_by_centre_row_equal_the_contiguous_call(models, gpu_devi
         d.free()
 
 
-def test_layer_major_experiment_kernel_is_refused_or_agrees(gpu_device):
-    """DM_PREC_F16X3_LM (tools/experiments/f16lm) is not part of the product build: the library refuses it unless it was
-    built with -DDM_WITH_F16X3_LM, in which case it has to pass the same parity check as the product kernels."""
+def test_wave_pair_experiment_kernel_is_refused_or_bit_identical(gpu_device):
+    """DM_PREC_F16X3_ROLES (tools/experiments/f16r, round 4) is not part of the product build: the library refuses it unless it was
+    built with -DDM_WITH_F16X3_ROLES, in which case its output equals the default kernel's bit for bit (same arithmetic, same order)."""
     from deepmod_amd import _lib
     w = synth.synthetic_weights(26, 4.0)
-    x = synth.synthetic_windows(1000, seed=12)
     m = model.BiLSTMModel(w, device=gpu_device)
-    if not m.get_info(_lib.DM_INFO_HAS_F16X3_LM):
+    if not m.get_info(_lib.DM_INFO_HAS_F16X3_ROLES):
         with pytest.raises(_lib.DeepModHipError):
-            m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3_LM)
+            m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3_ROLES)
         assert m.get_info(_lib.DM_INFO_PRECISION) == _lib.DM_PREC_F16X3
     else:
-        m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3_LM)
-        prob, cls = m.predict_windows(x)
-        _check(prob, cls, *oracle_np.predict_windows_c(w, x))
+        for n in (1, 129, 4097, 70000):
+            x = synth.synthetic_windows(n, seed=12 + n)
+            m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3)
+            prob, cls = m.predict_windows(x)
+            m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3_ROLES)
+            prob_r, cls_r = m.predict_windows(x)
+            assert np.array_equal(prob.view(np.uint32), prob_r.view(np.uint32)) and np.array_equal(cls, cls_r), n
     m.close()
 
 

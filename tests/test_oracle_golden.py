@@ -34,6 +34,24 @@ def test_oracle_matches_interpreted_reference_graph(path):
         assert np.array_equal(cls_n, g["cls"])
 
 
+def test_oracle_matches_interpreted_reference_graph_on_trained_like_weights():
+    """The same pin on weights with TRAINED statistics (tests/golden/make_trained_like.py: outlier kernel entries up to 1.7 beside a
+    median of 0.05, learnt biases): the reference's serialized graph, evaluated by tools/graphdef_interp.py, on 64 planted + 64 config-2
+    windows."""
+    from conftest import trained_like_weights
+    w = trained_like_weights()
+    assert set(w) == set(n for n, _ in synth.variable_shapes())
+    for n, shape in synth.variable_shapes():
+        assert w[n].shape == shape
+    g = np.load(os.path.join(GOLDEN, "trained_like_case.npz"))
+    prob_c, cls_c = oracle_np.predict_windows_c(w, g["X"])
+    assert np.abs(prob_c - g["prob"]).max() <= 5e-6
+    assert np.array_equal(cls_c, g["cls"])
+    prob_n, cls_n, _ = oracle_np.predict_windows_np(w, g["X"])
+    assert np.abs(prob_n - g["prob"]).max() <= 1e-6
+    assert 0.02 < g["cls"].mean() < 0.98           # both classes occur
+
+
 def test_oracle_thread_count_invariant():
     w = synth.synthetic_weights(3, 1.0)
     x = synth.synthetic_windows(97, seed=9)

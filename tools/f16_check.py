@@ -1,5 +1,5 @@
 """Dev tool: parity + speed of the split-f16 kernels vs the oracle and the fp32 kernel (run on the GPU box).
-DM_PRECS=f32,f16x3,f16x3lm picks the kernels, DM_LIB a dev build of the library, DM_REPS the launches timed."""
+DM_PRECS=f32,f16x3,f16x3r picks the kernels, DM_LIB a dev build of the library, DM_REPS the launches timed."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -7,7 +7,7 @@ from deepmod_amd import _lib, model, synth
 from oracle import oracle_np
 if os.environ.get('DM_LIB'):
     _lib.LIB_PATH = os.path.abspath(os.environ['DM_LIB'])
-precs = os.environ.get('DM_PRECS', 'f32,f16x3,f16x3lm').split(',')
+precs = os.environ.get('DM_PRECS', 'f32,f16x3,f16x3r').split(',')
 for scale in (1.0, 4.0):
     w = synth.synthetic_weights(21, scale)
     m = model.BiLSTMModel(w, 0)

@@ -7,12 +7,17 @@ from deepmod_amd import model, synth
 from oracle import oracle_np
 N = int(os.environ.get('DM_N', '1000000'))
 x = synth.synthetic_windows(N, seed=20260928)
-for seed, scale in ((17, 4.0), (26, 4.0), (17, 1.0)):
-    w = synth.synthetic_weights(seed, scale)
+def trained_like():
+    z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'trained_like_weights.npz'))
+    return {k.replace('|', '/'): np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
+
+
+for seed, scale in (('trained-like', 0.0), (17, 4.0), (26, 4.0), (17, 1.0)):
+    w = trained_like() if seed == 'trained-like' else synth.synthetic_weights(seed, scale)
     t0 = time.time()
     ref = np.concatenate([oracle_np.predict_windows_c(w, x[o:o + 65536])[0] for o in range(0, N, 65536)])
     m = model.BiLSTMModel(w, 0)
-    line = "weights seed %d scale %g, %d windows (oracle %.0f s):" % (seed, scale, N, time.time() - t0)
+    line = "weights seed %s scale %g, %d windows (oracle %.0f s), class-1 fraction %.3f:" % (seed, scale, N, time.time() - t0, float((ref[:, 1] > 0.5).mean()))
     for prec in ('f16x3', 'f16i8', 'f32'):
         m.set_precision(prec)
         p = np.concatenate([m.predict_windows(x[o:o + 65536])[0] for o in range(0, N, 65536)])

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of the bench command.
-# Usage: bash tools/profile_round.sh <tag> [f16x3|f16x3lm|f32]     -> gpurun_out/prof_<tag>/...
+# Usage: bash tools/profile_round.sh <tag> [f16x3|f16x3r|f32]     -> gpurun_out/prof_<tag>/...
 TAG=${1:-final}
 PREC=${2:-f16x3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}

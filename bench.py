@@ -22,6 +22,10 @@ import time
 
 import numpy as np
 
+# RCCL between the ranks of a node needs the ROCr runtime's dmabuf IPC mode on this stack (deepmod_amd/_lib.py): set before torch
+# (which initialises the runtime under torch.distributed.run) is imported
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -104,12 +108,43 @@ def cpu_baseline(weights, x_sample_src):
     chunks = [sample[i:i + 512] for i in range(0, 4096, 512)]
     b512, n512, dt512 = _timed(lambda: [oracle_np.predict_windows_c(weights, c, nthreads=cores) for c in chunks], 4096, 6.0)
     one, n_one, dt_one = _timed(run(sample[:1024], 1), 1024, 6.0)
+    gemm = cpu_gemm_baseline(weights, sample, cores)
     return (ref_prob, ref_cls), {"value": big, "unit": "base-positions/s", "cores": cores, "cores_why": why, "logical_cpus": os.cpu_count(), "kind": "port",
             "sample": "%d windows (passes over the first 16,384 windows of batch 0) in %.1f s, oracle/deepmod_oracle.c = fp32 C "
                       "restatement of the TF graph with libm expf/tanhf (scalar-ish loop nest, ~0.4 TFLOP/s; NOT TensorFlow/Eigen), "
                       "%d OpenMP threads" % (n_big, dt_big, cores),
             "batch512": {"value": b512, "cores": cores, "sample": "%d windows as calls of 512 (rnn_pred_batch_size, myDetect.py:30) in %.1f s" % (n512, dt512)},
-            "single_thread": {"value": one, "cores": 1, "sample": "%d windows in %.1f s" % (n_one, dt_one)}}
+            "single_thread": {"value": one, "cores": 1, "sample": "%d windows in %.1f s" % (n_one, dt_one)},
+            "gemm": gemm}
+
+
+def cpu_gemm_baseline(weights, sample, cores):
+    """A fairer stand-in for what TensorFlow-CPU does with this graph: the same 67 MatMuls as LIBRARY sgemm calls with
+    vectorised sigmoid / tanh on all usable cores - oracle/oracle_torch.py (torch-CPU addmm + intra-op threads; numpy / OpenBLAS,
+    oracle/oracle_np.predict_windows_np, if torch is not importable).  Batch 512 (rnn_pred_batch_size, myDetect.py:30) and 16,384.
+    Still NOT TensorFlow.  (The graph is elementwise-heavy - 33,000 transcendentals per window against K <= 200 GEMMs - so the library
+    form is not the 3-6x a dense-GEMM graph would gain over the C loop nest.)"""
+    out = {"kind": "port", "cores": cores}
+    try:
+        from oracle import oracle_torch
+        g = oracle_torch.TorchGraph(weights, cores)
+        fn = g.predict
+        out["what"] = ("oracle/oracle_torch.py: the graph as torch-CPU library calls (addmm = library sgemm per (step, layer, direction), vectorised "
+                       "sigmoid / tanh, %d intra-op threads): the GEMM-library restatement of the path, approximately what TF-CPU / Eigen would do; "
+                       "NOT TensorFlow" % cores)
+    except Exception as exc:
+        from oracle import oracle_np
+        fn = lambda x: oracle_np.predict_windows_np(weights, x)[0]
+        out["what"] = "oracle/oracle_np.predict_windows_np (numpy / OpenBLAS sgemm; torch not importable: %r); NOT TensorFlow" % (exc,)
+    for name, batch, budget in (("batch512", 512, 4.0), ("batch16384", 16384, 6.0)):
+        x = sample[:batch]
+        try:
+            v, n, dt = _timed(lambda: fn(x), batch, budget)
+            out[name] = {"value": v, "unit": "base-positions/s", "sample": "%d windows as calls of %d in %.1f s" % (n, batch, dt)}
+        except Exception as exc:      # a leg that cannot run must not cost the line
+            out[name] = {"error": repr(exc)}
+    out["value"] = (out.get("batch16384") or {}).get("value")
+    return out
 
 
 KERNEL_SOURCES = {"f16x3": ["lstm_f16s.hip.inc"], "f16i8": ["lstm_f16s.hip.inc"], "f32": ["lstm_f32.hip.inc"]}
@@ -141,6 +176,7 @@ def measured_traffic(precision):
         except Exception:
             continue
         return {"bytes": 2.0 * fetch + write, "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
+                "kernel_ms_rocprof_steady": pmc.get("kernel_ms_rocprof_steady"), "kernel_trace": pmc.get("kernel_trace"),
                 "source": os.path.relpath(path, ROOT), "windows_per_launch": pmc.get("windows_per_launch", BATCH),
                 "profiled_kernel_src_sha": pmc.get("kernel_src_sha"), "kernel_src_sha": kernel_source_sha(precision),
                 "stale": pmc.get("kernel_src_sha") != kernel_source_sha(precision)}
@@ -196,26 +232,65 @@ def parity_field(m, x_sample, ref):
 
 
 def extras(m, _lib, model, precision, x_dev0, x_host0, prob_dev, cls_dev, reps=4):
-    """Untimed-for-`value` side measurements on rank 0 at N = 1: the other MFMA modes on the same batch (kernel
-    time from HIP events) and the PCIe-inclusive rate when the boundary is handed pageable host buffers."""
+    """Untimed-for-`value` side measurements on rank 0 at N = 1: the other MFMA modes on the same batch and the PCIe-inclusive rate
+    when the boundary is handed pageable host buffers.  The other modes are timed LIKE THE MAIN LEG: asynchronous
+    launches on the in-order queue, SETUP_LAUNCHES untimed launches of THAT mode first (the power / clock state of a mode is its own),
+    then >= 64 timed launches, kernel time from HIP events."""
     out = {}
-    m.set_option(_lib.DM_OPT_ASYNC, 0)
+    m.set_option(_lib.DM_OPT_ASYNC, 1)
     for key, other in (("other_precision", "f32" if precision.startswith("f16") else "f16x3"),
                        ("opt_in_precision", "f16i8" if precision != "f16i8" else "f16x3")):
         m.set_precision(other)
-        m.predict_windows(x_dev0, prob=prob_dev, cls=cls_dev)
-        m.sync()
-        m.profile_reset()
-        for _ in range(reps if other == "f32" else 4 * reps):
+        n_timed = 64 if other != "f32" else 32
+        for _ in range(SETUP_LAUNCHES if other != "f32" else 8):
             m.predict_windows(x_dev0, prob=prob_dev, cls=cls_dev)
         m.sync()
+        m.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(n_timed):
+            m.predict_windows(x_dev0, prob=prob_dev, cls=cls_dev)
+        m.sync()
+        wall = time.perf_counter() - t0
         ms, launches, kw = m.profile_get()
         rate = kw / (ms * 1e-3)
         Q = PRECISIONS[other]
-        out[key] = {"precision": other, "kernel": Q["kernel"], "avg_launch_ms": ms / max(launches, 1),
-                    "windows_per_s_kernel": rate, "achieved_tflops": rate * FLOP_PER_WINDOW / 1e12,
-                    "peak_tflops": Q["peak"], "frac": rate * FLOP_PER_WINDOW / 1e12 / Q["peak"], "label": Q["label"]}
+        out[key] = {"precision": other, "kernel": Q["kernel"], "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+                    "windows_per_s_kernel": rate, "windows_per_s_wall": n_timed * BATCH / wall, "achieved_tflops": rate * FLOP_PER_WINDOW / 1e12,
+                    "peak_tflops": Q["peak"], "frac": rate * FLOP_PER_WINDOW / 1e12 / Q["peak"], "label": Q["label"],
+                    "timing": "%d untimed + %d timed asynchronous launches of this mode back to back" % (SETUP_LAUNCHES if other != "f32" else 8, n_timed)}
     m.set_precision(precision)
+    m.set_option(_lib.DM_OPT_ASYNC, 0)
+    # a model with TRAINED weight statistics (tests/golden/trained_like_weights.npz: the reference's own .data shards are absent) loaded
+    # the way the command line loads a model: precision "auto" = the load-time calibration gate decides whether the int8 cross-term mode
+    # may stand in for the three-product kernel (dm_model_calibrate_i8).  Same batch, same timing as the main leg.
+    try:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "trained_like_weights.npz"))
+        wt = {k.replace("|", "/"): np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
+        t0 = time.perf_counter()
+        mt = model.BiLSTMModel(wt, device=m.device, precision="auto")
+        t_load = time.perf_counter() - t0
+        mt.set_option(_lib.DM_OPT_PROFILE, 1)
+        mt.set_option(_lib.DM_OPT_ASYNC, 1)
+        for _ in range(SETUP_LAUNCHES):
+            mt.predict_windows(x_dev0, prob=prob_dev, cls=cls_dev)
+        mt.sync()
+        mt.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(64):
+            mt.predict_windows(x_dev0, prob=prob_dev, cls=cls_dev)
+        mt.sync()
+        wall = time.perf_counter() - t0
+        ms, launches, kw = mt.profile_get()
+        chosen = {_lib.DM_PREC_F16X3: "f16x3", _lib.DM_PREC_F16I8: "f16i8", _lib.DM_PREC_F32: "f32"}[mt.get_info(_lib.DM_INFO_PRECISION)]
+        rate = kw / (ms * 1e-3)
+        out["trained_like_model"] = {"weights": "tests/golden/trained_like_weights.npz (tests/golden/make_trained_like.py: the exact architecture trained on a planted "
+                                                "per-5-mer signal; kernel |w| median 0.05, max 1.7)",
+                                     "precision_requested": "auto", "calibration": mt.calibration, "precision_selected": chosen,
+                                     "model_load_s_including_calibration": t_load, "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+                                     "windows_per_s_kernel": rate, "windows_per_s_wall": 64 * BATCH / wall,
+                                     "frac": rate * FLOP_PER_WINDOW / 1e12 / PRECISIONS[chosen]["peak"], "weights_obj": wt, "model_obj": mt}
+    except Exception as exc:
+        out["trained_like_model"] = {"error": repr(exc)}
     m.predict_windows(x_host0)            # host in, host out: H2D + kernel + D2H, synchronous
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -225,6 +300,79 @@ def extras(m, _lib, model, precision, x_dev0, x_host0, prob_dev, cls_dev, reps=4
                            "note": "dm_predict_windows on pageable host x[65536,21,7] fp32, prob+cls returned to host "
                                    "(PCIe-inclusive, 588 B in + 9 B out per window); never used as `value`"}
     return out
+
+
+# ---- extras.e2e: BASELINE configs[2] at full size through the CLI ----
+E2E_GENOME_LEN, E2E_COVERAGE, E2E_READS_PER_FILE, E2E_CHROM = 4_641_652, 30.0, 100, "NC_000913.3"
+# sha256 of the two BED files the command writes for this input with the default kernel (deterministic: integer counters, a
+# deterministic classifier; profiles/r04/bench_f16x3.json).  A different digest = different BED bytes.
+E2E_EXPECTED_BED_SHA256 = {"+": "a3c4928333e7492181141c0b77219a5043d1269dd3553cbbed62352df360dda3",
+                            "-": "d065fd604d33d764ed986b12e365a0bdbd616f29b827ab94469843a3f3e06b4f"}
+
+
+def _e2e_gen(args):
+    from deepmod_amd import synth_reads
+    out_dir, first, n = args
+    return synth_reads.write_synthetic_packed_run(out_dir, E2E_GENOME_LEN, E2E_COVERAGE, E2E_READS_PER_FILE, seed=1, chrom=E2E_CHROM,
+                                                  first_file=first, n_files=n)
+
+
+def e2e_leg(precision):
+    """configs[2] (E. coli 4.64 Mb at 30x: 23,300 synthetic reads, 1.39e8 base-positions) from packed feature containers on disk to
+    the two BED files through `bin/DeepMod.py detect` with TWO feeder processes and the command's defaults: the wall time of the whole
+    command (interpreter start to exit), what it classified, and the digest of what it wrote.  Input generation is untimed."""
+    import hashlib, multiprocessing, re, shutil, subprocess, tempfile
+    from deepmod_amd import synth
+    cores, _ = usable_cores()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 12e9 else None
+    tmp = tempfile.mkdtemp(prefix="dm_bench_e2e_", dir=base)
+    try:
+        wrk = os.path.join(tmp, "reads")
+        total_files = int(np.ceil(E2E_COVERAGE * E2E_GENOME_LEN / 6000.0 / E2E_READS_PER_FILE))
+        nproc = max(1, min(32, cores))
+        chunk = int(np.ceil(total_files / nproc))
+        t0 = time.perf_counter()
+        with multiprocessing.get_context("spawn").Pool(nproc) as pool:
+            files = sum(pool.map(_e2e_gen, [(wrk, i, chunk) for i in range(0, total_files, chunk)]), [])
+        t_gen = time.perf_counter() - t0
+        prefix = os.path.join(tmp, "model", "mod_train_synth")
+        os.makedirs(os.path.dirname(prefix))
+        synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)
+        out = os.path.join(tmp, "out")
+        cmd = [sys.executable, os.path.join(ROOT, "bin", "DeepMod.py"), "detect", "--wrkBase", wrk, "--modfile", prefix, "--outFolder", out,
+               "--Base", "C", "--gpus", "1", "--threads", "2", "--FileID", "stream"]
+        t0 = time.perf_counter()
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+        if res.returncode != 0:
+            return {"error": "bin/DeepMod.py detect exited %d: %s" % (res.returncode, (res.stdout[-500:] + res.stderr[-1500:]))}
+        m1 = re.search(r"Streaming detect: (\d+) reads, (\d+) base-positions", res.stdout)
+        m2 = re.search(r"windows run through the classifier: (\d+) of", res.stdout)
+        reads, n_pos = (int(m1.group(1)), int(m1.group(2))) if m1 else (None, None)
+        n_win = int(m2.group(1)) if m2 else None
+        sha, lines = {}, {}
+        for strand in "+-":
+            path = "%s/stream/mod_pos.%s%s.C.bed" % (out, E2E_CHROM, strand)
+            h = hashlib.sha256()
+            nl = 0
+            with open(path, "rb") as fh:
+                for blk in iter(lambda: fh.read(1 << 24), b""):
+                    h.update(blk)
+                    nl += blk.count(b"\n")
+            sha[strand], lines[strand] = h.hexdigest(), nl
+        expected = E2E_EXPECTED_BED_SHA256 if precision == "f16x3" else {"+": None, "-": None}
+        return {"config": "configs[2]: E. coli 4.64 Mb at 30x, packed feature containers -> bin/DeepMod.py detect --threads 2 (two feeder processes, "
+                          "streaming mode, default options) -> 2 BED files, 1 GPU", "input_files": len(files), "input_generation_s_untimed": t_gen,
+                "wall_s": wall, "reads": reads, "base_positions": n_pos, "windows_classified": n_win,
+                "base_positions_per_s": n_pos / wall if n_pos else None, "windows_per_s": n_win / wall if n_win else None,
+                "units_note": "base_positions counts every aligned base of the run; the streaming command classifies only the windows centred "
+                              "on the base of interest (no other class can reach the BED, myDetect.py:1091) - windows_per_s is the rate in the "
+                              "unit of `value`, over the WHOLE command (process start-up, model load, BED writing included)",
+                "bed_lines": lines, "bed_sha256": sha, "bed_sha256_expected": expected,
+                "bed_matches_expected": (all(sha[k] == expected[k] for k in "+-") if all(expected.values()) else None),
+                "stdout_tail": res.stdout.strip().splitlines()[-5:-1]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 class _FileControl:
@@ -262,7 +410,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=sorted(PRECISIONS), default="f16x3",
                     help="MFMA mode of the classifier kernel (f16x3 and f32 meet the 1e-4 probability tolerance; f16i8 is the opt-in reduced-precision mode)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (other precision, host-buffer rate)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (other precision, host-buffer rate, e2e)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip extras.e2e (configs[2] through bin/DeepMod.py detect: ~6 GB of synthetic input in /dev/shm or /tmp)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -430,6 +579,7 @@ def main():
                          "frac": achieved / P["peak"], "traffic": (traffic or {}).get("bytes"),
                          "traffic_detail": traffic, "algorithmic_bytes": 596 * BATCH,
                          "kernel": P["kernel"], "avg_launch_ms": avg_launch_s * 1e3,
+                         "kernel_ms_rocprof_steady": (traffic or {}).get("kernel_ms_rocprof_steady"),      # the same launches under rocprofv3, set-up launches dropped (committed profile, another box)
                          "launches": launches, "flop_per_window": FLOP_PER_WINDOW,
                          "peak_note": P["peak_note"],
                          "matrix_pipe_busy_est": achieved * P.get("issued_per_algorithmic", 1.0) / P["peak"],
@@ -449,10 +599,23 @@ def main():
                                 "rccl_error": comm_error, "per_rank": per_rank, "measured_on_hardware_with_more_than_one_rank": bool(world > 1 and os.environ.get("DM_BENCH_ONE_DEVICE") != "1")}
         if world == 1 and not args.no_extras:
             out["extras"] = extras(m, _lib, model, args.precision, x_dev[0], x0, prob_dev, cls_dev)
+            if not args.no_e2e and args.precision == "f16x3":
+                try:
+                    out["extras"]["e2e"] = e2e_leg(args.precision)
+                except Exception as exc:
+                    out["extras"]["e2e"] = {"error": repr(exc)}
+        tl = (out.get("extras") or {}).get("trained_like_model") or {}
+        wt, mt = tl.pop("weights_obj", None), tl.pop("model_obj", None)
         if world == 1 and not args.no_cpu_baseline:
             ref, out["cpu_baseline"] = cpu_baseline(weights, x0)
             m.set_option(_lib.DM_OPT_ASYNC, 0)
             out["parity"] = parity_field(m, x0[:16384], ref)
+            if mt is not None:            # the gate-selected mode of the trained-like model against the oracle on the same windows
+                from oracle import oracle_np
+                mt.set_option(_lib.DM_OPT_ASYNC, 0)
+                tl["parity"] = parity_field(mt, x0[:16384], oracle_np.predict_windows_c(wt, x0[:16384]))
+        if mt is not None:
+            mt.close()
         try:      # RCCL prints its version banner through C stdio: push it out first so that the JSON line is the last line
             import ctypes
             ctypes.CDLL(None).fflush(None)

@@ -6,6 +6,12 @@ import ctypes
 import os
 from typing import Optional
 
+# Multi-process GPU work on this stack (RCCL communicators between the ranks of a node) needs the ROCr runtime in its dmabuf IPC mode: the
+# host driver does not support the legacy IPC handles, and with them hipIpcGetMemHandle - hence ncclCommInitRank's buffer exchange -
+# fails with "invalid argument".  The runtime reads the variable when it initialises (the first HIP call of the process), so it is set
+# here, before the library is loaded, unless the caller has decided otherwise.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libdeepmod_hip.so")
 
@@ -39,6 +45,7 @@ SIGNATURES = [
     ("dm_model_destroy", None, [_vp]),
     ("dm_model_set_option", _c.c_int, [_vp, _c.c_int, _i64]),
     ("dm_model_get_info", _c.c_int, [_vp, _c.c_int, _c.POINTER(_i64)]),
+    ("dm_model_calibrate_i8", _c.c_int, [_vp, _i64, _c.c_double, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int)]),
     ("dm_predict_windows", _c.c_int, [_vp, _vp, _i64, _vp, _vp]),
     ("dm_predict_read", _c.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     ("dm_predict_read_at", _c.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),

@@ -606,6 +606,27 @@ def _run_stored_detect(moptions, ctx, pmanager, items, ngpu):
     return ledger
 
 
+# what one feeder process prepares per second (profiles/r03/e2e_rate.txt) against what one GPU classifies: packed feature containers
+# 6.4e7 rows/s per feeder - one or two feed a GPU; raw containers (signal statistics + alignment walk + rows) 1.7e7 - four to six do
+RAW_FEEDERS_PER_GPU = 4
+
+
+def feeder_budget(threads: int, world: int, usable_cpus: int, raw_input: bool):
+    """How the host cores of a streaming run are shared out: (feeder threads per rank asked for, feeder PROCESSES per rank, warning or
+    None).  `--threads` is the total over all ranks; a rank gets threads // world feeders, within the CPUs this job may use once every
+    rank's own process (device queue, uploads, the signal server of raw input) has one: (usable_cpus - world) // world.  On a 16-CPU
+    allowance with 8 GPUs that is ONE feeder per GPU - enough for packed feature containers, a third of what a GPU takes from raw
+    containers: the run goes on, feeder-bound, and says so once."""
+    world = max(1, int(world))
+    feeders = max(1, int(threads) // world)
+    procs = max(1, min(feeders, (int(usable_cpus) - world) // world))
+    warning = None
+    if raw_input and procs < RAW_FEEDERS_PER_GPU:
+        warning = ("Warning: %d feeder process(es) per GPU (--threads %d over %d GPU(s), %d usable CPUs): raw input needs about %d per GPU to "
+                   "keep it busy - this run will be bound by its feeders" % (procs, threads, world, usable_cpus, RAW_FEEDERS_PER_GPU))
+    return feeders, procs, warning
+
+
 def _run_streaming_detect(moptions, ctx, pmanager, items, ngpu):
     """One process per GPU (rank), work items pulled from one shared queue by all ranks, counters merged with RCCL
     (deepmod_amd/stream.py).  -> (error ledger, per-rank stats)"""
@@ -618,15 +639,17 @@ def _run_streaming_detect(moptions, ctx, pmanager, items, ngpu):
     if os.path.isdir(rdv):
         for f in os.listdir(rdv):
             os.remove(os.path.join(rdv, f))
-    feeders = max(1, moptions['threads'] // world)
-    # the host side of a batch is prepared by feeder PROCESSES of each rank (threads serialise on the interpreter lock): as
-    # many as --threads asks for, within the CPUs this job may use (one is left to each rank's device queue)
-    feeder_procs = max(1, min(feeders, (stream.usable_cpus() - world) // world)) if moptions.get('feeder_procs', 1) else 0
+    from . import rawreads
+    raw_input = any(f.endswith(rawreads.RAW_SUFFIX) for it in items for f in it[0])
+    feeders, feeder_procs, warning = feeder_budget(moptions['threads'], world, stream.usable_cpus(), raw_input)
+    if not moptions.get('feeder_procs', 1):
+        feeder_procs = 0
+    elif warning:
+        print(warning)
     # raw containers: the signal stage of all feeders runs in the GPU process (stream.signal_server).  Without it every
     # feeder owns a HIP context, and beyond ~8 such processes per GPU the hardware queues are oversubscribed (8 feeders
     # 9.1e6 base-positions/s, 11 feeders 6.3e6 with the device queue waiting 2.9 of 4.3 s - profiles/r02/README.md)
-    from . import rawreads
-    if not run_opts.get('signal_server', True) and any(f.endswith(rawreads.RAW_SUFFIX) for it in items for f in it[0]):
+    if not run_opts.get('signal_server', True) and raw_input:
         feeder_procs = min(feeder_procs, int(moptions.get('feeder_procs_raw', 8)))
     ledger, stats = defaultdict(list), []
 

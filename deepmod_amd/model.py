@@ -125,14 +125,35 @@ class BiLSTMModel:
         self._h = self._lib.dm_model_create(device, flat.ctypes.data, flat.size, NFEAT, HID, WIN, LAYERS)
         if not self._h:
             raise _lib.DeepModHipError("dm_model_create: " + _lib.last_error())
-        # library default is "f16x3" (split-f16 MFMA, fp32-class results); DEEPMOD_PRECISION=f32 selects the fp32 MFMA kernel
+        # library default is "f16x3" (split-f16 MFMA, fp32-class results); DEEPMOD_PRECISION=f32 selects the fp32 MFMA kernel,
+        # "auto" runs the load-time calibration gate of the int8 mode (calibrate_i8)
         precision = precision or os.environ.get("DEEPMOD_PRECISION")
+        self.calibration = None
         if precision:
             self.set_precision(precision)
 
+    # the gate of "auto": 2^18 synthetic windows through the fp32 and the int8 kernel (~35 ms), int8 only if they agree to 4e-5 - a
+    # quarter of the sample and a stricter bound than the 5e-5 on 10^6 windows it stands for (profiles/r04/i8_tail.txt: weights with
+    # trained statistics 1.2e-5 in the tail of 10^6 windows; U(-a, a) kernels at scale 4 7e-5 - 1.1e-4: refused)
+    CALIB_WINDOWS, CALIB_BOUND = 1 << 18, 4e-5
+
+    def calibrate_i8(self, n_windows: Optional[int] = None, bound: Optional[float] = None):
+        """dm_model_calibrate_i8 -> (largest |p(f32) - p(f16i8)| on the calibration windows, whether DM_PREC_F16I8 was selected)."""
+        err, sel = ctypes.c_double(), ctypes.c_int()
+        _lib.check(self._lib.dm_model_calibrate_i8(self._h, int(n_windows or self.CALIB_WINDOWS), float(bound or self.CALIB_BOUND),
+                                                   ctypes.byref(err), ctypes.byref(sel)))
+        self.calibration = {"max_abs_dp": err.value, "selected_f16i8": bool(sel.value), "windows": int(n_windows or self.CALIB_WINDOWS),
+                            "bound": float(bound or self.CALIB_BOUND)}
+        return err.value, bool(sel.value)
+
     def set_precision(self, name: str):
+        if name == "auto":
+            if self.get_info(_lib.DM_INFO_F16_REPRESENTABLE):
+                self.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3)
+                self.calibrate_i8()
+            return
         if name not in self.PRECISIONS:
-            raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
+            raise ValueError("precision must be one of %s" % sorted(list(self.PRECISIONS) + ["auto"]))
         self.set_option(_lib.DM_OPT_PRECISION, self.PRECISIONS[name])
 
     @classmethod
@@ -268,11 +289,13 @@ class Session:
         self.device = device
         self.model: Optional[BiLSTMModel] = None
 
+    # the command-line path (every model the detect command loads comes through here): DM_PREC_F16X3 unless the model's own calibration
+    # lets the int8 mode in (BiLSTMModel.calibrate_i8); DEEPMOD_PRECISION = f16x3 / f32 / f16i8 / auto overrides
     def restore(self, prefix: str):
-        self.model = BiLSTMModel.from_checkpoint(prefix, self.device)
+        self.model = BiLSTMModel(tfbundle.load_bundle(prefix), self.device, precision=os.environ.get("DEEPMOD_PRECISION", "auto"))
 
     def load_tensors(self, tensors: Dict[str, np.ndarray]):
-        self.model = BiLSTMModel(tensors, self.device)
+        self.model = BiLSTMModel(tensors, self.device, precision=os.environ.get("DEEPMOD_PRECISION", "auto"))
 
     def run(self, fetches, feed_dict=None):
         single = not isinstance(fetches, (list, tuple))

@@ -19,25 +19,37 @@ from . import _lib, features, predstore
 OUTPUT_WARNING = 2   # myCom.py:7 (OUTPUT_DEBUG 0, OUTPUT_INFO 1, OUTPUT_WARNING 2, OUTPUT_ERROR 3)
 
 
+# SAM fields of a record and the checks that make it unusable, in the order the reference tests them (the status strings are contract:
+# the error ledger is keyed by them, myDetect.py:931-936).  An int() of a malformed field raises ValueError as it does there.
+_SAM_FIELDS = ('qname', 'flag', 'rname', 'pos', 'mapq', 'cigar')
+_UNUSABLE = (
+    ("qname is *", lambda r: r['qname'] == '*'),
+    ("mapq is 255", lambda r: int(r['mapq']) == 255),
+    ("pos is 0", lambda r: int(r['pos']) == 0),
+    ("cigar is *", lambda r: r['cigar'] == '*'),
+    ("rname is *", lambda r: r['rname'] == '*'),
+)
+
+
 def handle_line(moptions, sp_param, f5align):
-    """One SAM line -> f5align[qname] = (mapq, flag, rname, pos, cigar, seq), best mapq wins (myDetect.py:929-943)."""
-    lsp = sp_param['line'].split('\t')
-    qname, flag, rname, pos, mapq, cigar, _, _, _, seq, _ = lsp[:11]
-    if qname == '*':
-        sp_param['f5status'] = "qname is *"
-    elif int(mapq) == 255:
-        sp_param['f5status'] = "mapq is 255"
-    elif int(pos) == 0:
-        sp_param['f5status'] = "pos is 0"
-    elif cigar == '*':
-        sp_param['f5status'] = "cigar is *"
-    elif rname == '*':
-        sp_param['f5status'] = "rname is *"
-    if not sp_param['f5status'] == "":
-        return qname
-    if (qname not in f5align) or f5align[qname][0] < int(mapq):
-        f5align[qname] = (int(mapq), int(flag), rname, int(pos), cigar, seq)
-    return qname
+    """One SAM line (sp_param['line']) -> f5align[qname] = (mapq, flag, rname, pos, cigar, seq); of several records of a read the one
+    with the best mapq is kept; a record that cannot be used sets sp_param['f5status'] to the first reason that applies and changes
+    nothing else (behaviour of myDetect.py:929-943).  Returns qname."""
+    cols = sp_param['line'].split('\t')
+    if len(cols) < 11:
+        raise ValueError('a SAM record has 11 mandatory fields, this line has %d' % len(cols))
+    rec = dict(zip(_SAM_FIELDS, cols[:6]))
+    rec['seq'] = cols[9]
+    reason = next((status for status, applies in _UNUSABLE if applies(rec)), None)
+    if reason is not None:
+        sp_param['f5status'] = reason
+    if sp_param['f5status'] != "":          # (also a status an earlier step of this read left behind)
+        return rec['qname']
+    mapq = int(rec['mapq'])
+    best = f5align.get(rec['qname'])
+    if best is None or best[0] < mapq:
+        f5align[rec['qname']] = (mapq, int(rec['flag']), rec['rname'], int(rec['pos']), rec['cigar'], rec['seq'])
+    return rec['qname']
 
 
 _fasta_cache: Dict[str, Dict[str, str]] = {}

@@ -110,9 +110,29 @@ def c_oracle() -> ctypes.CDLL:
     return _LIB
 
 
+def usable_cores() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota.  A container that shows 256 logical CPUs but is
+    throttled to 16 would otherwise run the oracle's OpenMP loops with 256 threads on 16 CPUs (measured on the GPU boxes: the config-1
+    test's oracle pass 6x slower)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
 def predict_windows_c(weights: Dict[str, np.ndarray], x: np.ndarray, nthreads: int = 0,
                       want_hcat: bool = False):
+    """nthreads = 0: as many OpenMP threads as this process has usable cores."""
     lib = c_oracle()
+    if nthreads <= 0:
+        nthreads = usable_cores()
     flat = flatten_weights(weights)
     x = np.ascontiguousarray(x, dtype=np.float32)
     n = x.shape[0]

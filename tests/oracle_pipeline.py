@@ -8,8 +8,14 @@ from oracle import detect_oracle, oracle_np
 
 def oracle_beds(files, weights, base):
     """-> ({(chr, strand): BED bytes}, smallest |p1 - 0.5| over all windows, number of windows)"""
-    classify = lambda x: oracle_np.predict_windows_c(weights, np.asarray(x, np.float32))[1]
-    by, margin, nwin = {}, 1.0, 0
+    state = {'margin': 1.0}
+
+    def classify(x):          # mPredict1's session stand-in; the smallest |p1 - 0.5| of the run is taken from the same oracle pass
+        prob, cls = oracle_np.predict_windows_c(weights, np.asarray(x, np.float32))
+        if len(prob):
+            state['margin'] = min(state['margin'], float(np.abs(prob[:, 1] - 0.5).min()))
+        return cls
+    by, nwin = {}, 0
     for f in files:
         for rd in predstore.load_feature_container(f):
             bmi = rd['base_map_info']
@@ -17,14 +23,10 @@ def oracle_beds(files, weights, base):
             n = len(ev_bases) - rd['start_clip'] - rd['end_clip']
             if n < 50:
                 continue
-            tx = np.asarray(rd['mfeatures'][:, 3:], np.float32)
-            win = np.lib.stride_tricks.sliding_window_view(tx, (21, 7))[:, 0][90:90 + n]
-            prob = oracle_np.predict_windows_c(weights, np.ascontiguousarray(win))[0]
-            margin = min(margin, float(np.abs(prob[:, 1] - 0.5).min()))
             nwin += n
             _, _, mod_pred = detect_oracle.mpredict1_oracle(rd['mfeatures'], list(bmi['readbase']), ev_bases, rd['start_clip'],
                                                             rd['end_clip'], classify)
             by.setdefault((rd['chr'], rd['strand']), []).append(
                 {'refbase': ''.join(bmi['refbase']), 'readbase': ''.join(bmi['readbase']),
                  'refbasei': [int(v) for v in bmi['refbasei']], 'mod_pred': mod_pred.tolist()})
-    return {k: detect_oracle.sum_handler_oracle(k[0], k[1], base, v) for k, v in by.items()}, margin, nwin
+    return {k: detect_oracle.sum_handler_oracle(k[0], k[1], base, v) for k, v in by.items()}, state['margin'], nwin

@@ -179,7 +179,7 @@ def test_two_rank_run_that_cannot_build_its_communicator_fails_fast_and_clean(tm
     t0 = time.time()
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'bin', 'DeepMod.py'), 'detect', '--wrkBase', str(wrk), '--modfile', prefix, '--outFolder', out,
                           '--FileID', 'two', '--threads', '4', '--Base', 'C', '--gpus', '2'], capture_output=True, text=True, timeout=300,
-                         env=dict(os.environ, DEEPMOD_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0'))
+                         env=dict(os.environ, DEEPMOD_ONE_DEVICE='1'))
     assert res.returncode != 0 and time.time() - t0 < 120
     assert 'ncclCommInitRank' in res.stderr and 'a streaming detect worker died' in res.stderr
     assert not os.path.exists(out + '/two.done') and not glob.glob(out + '/two/*.bed')

@@ -59,13 +59,28 @@ def test_permutation_equivariance_and_split_invariance(full_run):
         assert np.array_equal(pp, prob[idx[a:b]]) and np.array_equal(cc, cls[idx[a:b]])
 
 
-def test_oracle_spot_check(full_run):
-    w, _, x, prob, cls = full_run
-    idx = np.random.default_rng(6).choice(N, 8192, replace=False)
+def test_error_tail_of_the_default_and_the_fp32_kernel_against_the_oracle(full_run):
+    """The TAIL of the probability error, not a spot check: a stratified quarter of the 10^6 windows - every fourth
+    window plus the 1,000 windows nearest to p1 = 0.5, where a class can flip - against the fp32 C oracle, for the default (split-f16) and
+    the fp32 kernel.  Worst window of the full 10^6 (tools/i8_tail.py, profiles/r04/i8_tail.txt): 9.1e-6 / 8.5e-6; the bound asserted here,
+    3e-5, is what a change of the default's arithmetic would have to stay under."""
+    w, m, x, prob, cls = full_run
+    near_half = np.argsort(np.abs(prob[:, 1] - 0.5))[:1000]
+    idx = np.union1d(np.arange(0, N, 4), near_half)
     ref_prob, ref_cls = oracle_np.predict_windows_c(w, x[idx])
-    assert np.abs(prob[idx] - ref_prob).max() <= 1e-4
+    d = np.abs(prob[idx] - ref_prob).max(axis=1)
+    assert d.max() <= 3e-5, float(d.max())
     near = np.abs(ref_prob[:, 1] - 0.5) < 1e-4
     assert np.array_equal(cls[idx][~near], ref_cls[~near])
+    m.set_precision("f32")
+    try:
+        p32 = np.concatenate([m.predict_windows(x[idx[o:o + BATCH]])[0] for o in range(0, len(idx), BATCH)])
+    finally:
+        m.set_precision("f16x3")
+    d32 = np.abs(p32 - ref_prob).max(axis=1)
+    assert d32.max() <= 3e-5, float(d32.max())
+    print("error tail on %d windows (every 4th of 10^6 + the 1,000 nearest to a tie): f16x3 max %.3g p99.99 %.3g | f32 max %.3g p99.99 %.3g; %d near ties"
+          % (len(idx), float(d.max()), float(np.quantile(d, 0.9999)), float(d32.max()), float(np.quantile(d32, 0.9999)), int(near.sum())))
 
 
 def test_summary_of_a_million_bases(full_run, gpu_device):

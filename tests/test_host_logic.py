@@ -291,3 +291,21 @@ def test_bed_parts_join_to_bed_lines():
     shifted = summary.bed_lines('chrQ', '-', 'C', touch, cov, mod, first_pos=10 ** 9)
     assert b''.join(p.tobytes() for p in summary.bed_parts('chrQ', '-', 'C', touch, cov, mod, first_pos=10 ** 9, slice_positions=999, threads=4)) == shifted
     assert list(summary.bed_parts('chrQ', '+', 'C', np.zeros(100, np.int32), cov[:100], mod[:100])) == []
+
+
+def test_feeder_budget_of_a_streaming_run():
+    """detect.feeder_budget: --threads is the total over the ranks; a rank's feeder processes fit into the CPUs the
+    job may use after every rank's own process has one.  The driver's box (16 CPUs, 8 GPUs) leaves ONE feeder per GPU: enough for packed
+    containers, a warning for raw ones."""
+    from deepmod_amd.detect import feeder_budget
+    assert feeder_budget(threads=32, world=8, usable_cpus=16, raw_input=False) == (4, 1, None)
+    f, p, warn = feeder_budget(threads=32, world=8, usable_cpus=16, raw_input=True)
+    assert (f, p) == (4, 1) and warn and "1 feeder process(es) per GPU" in warn and "16 usable CPUs" in warn
+    assert feeder_budget(32, 8, 32, False) == (4, 3, None)
+    assert feeder_budget(32, 8, 32, True)[1] == 3 and feeder_budget(32, 8, 32, True)[2]
+    assert feeder_budget(64, 8, 256, True) == (8, 8, None)           # a full node: asked-for feeders fit, nothing to warn about
+    assert feeder_budget(16, 8, 256, False) == (2, 2, None)
+    assert feeder_budget(4, 1, 16, True) == (4, 4, None)
+    assert feeder_budget(1, 1, 2, False) == (1, 1, None)
+    assert feeder_budget(2, 8, 16, False) == (1, 1, None)            # fewer threads than ranks: still one per rank
+    assert feeder_budget(8, 1, 1, False) == (8, 1, None)             # never below one

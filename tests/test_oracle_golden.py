@@ -52,6 +52,16 @@ def test_oracle_matches_interpreted_reference_graph_on_trained_like_weights():
     assert 0.02 < g["cls"].mean() < 0.98           # both classes occur
 
 
+def test_torch_restatement_equals_c_oracle():
+    """oracle/oracle_torch.py (bench.py's cpu_baseline.gemm leg) is the same graph as the C oracle."""
+    from oracle import oracle_torch
+    w = synth.synthetic_weights(26, 4.0)
+    x = synth.synthetic_windows(300, seed=3)
+    p = oracle_torch.TorchGraph(w, 2).predict(x)
+    ref, _ = oracle_np.predict_windows_c(w, x)
+    assert np.abs(p - ref).max() <= 1e-5
+
+
 def test_oracle_thread_count_invariant():
     w = synth.synthetic_weights(3, 1.0)
     x = synth.synthetic_windows(97, seed=9)

@@ -126,6 +126,35 @@ def test_two_rank_streaming_engine_equals_single_process_and_oracle(tmp_path):
             assert outs[tag][k] == want[k], (tag, k)
 
 
+def test_eight_ranks_six_of_them_idle_uneven_contigs_and_a_contig_only_one_rank_saw(tmp_path):
+    """The driver's real world size: 8 ranks over gloo, 2 work items - six ranks never see a read and still take part
+    in every agreement and every merge (zeros); contig lengths 6001 and 5003 do not divide by 8 (the last slice is short); chrB reaches
+    one rank only.  The joined BED parts equal the oracle pipeline's bytes."""
+    from deepmod_amd import synth, synth_reads
+    fa = synth_reads.write_synthetic_run(str(tmp_path / 'a'), n_reads=6, reads_per_file=2, genome_len=6001, seed=13, chrom='chrA', min_len=120, max_len=400)
+    fb = synth_reads.write_synthetic_run(str(tmp_path / 'b'), n_reads=2, reads_per_file=2, genome_len=5003, seed=14, chrom='chrB', min_len=120, max_len=400)
+    all_files = fa + fb                                   # items: [a0, a1] -> rank 0, [a2, b0] -> rank 1; ranks 2..7: nothing
+    assert len(all_files) == 4
+    w = synth.synthetic_weights(26, 4.0)
+    want = _oracle_beds(all_files, w)
+    assert len(want) == 4
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "out8"
+    cfg = tmp_path / "cfg8.json"
+    cfg.write_text(json.dumps({"files": all_files, "out": str(out), "seed": 26, "scale": 4.0, "merge": "scatter"}))
+    env = dict(os.environ, DM_ROOT=ROOT, DM_CFG=str(cfg), OMP_NUM_THREADS="1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                          "--master-port", "29531", str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    stats = [json.load(open(out / ("stats.%d.json" % r))) for r in range(8)]
+    assert [s["reads"] > 0 for s in stats] == [True, True] + [False] * 6
+    assert sum(s["reads"] for s in stats) == 8
+    for k in want:
+        assert open('%s/mod_pos.%s%s.C.bed' % (out, k[0], k[1]), 'rb').read() == want[k], k
+    assert not [f for f in os.listdir(out) if '.part' in f]
+
+
 def test_shard_partitions_everything():
     from deepmod_amd import comm
     items = list(range(23))

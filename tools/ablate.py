@@ -37,6 +37,7 @@ VARIANTS = {
     # round 4: the operand-toggle dial (tools/lo_trunc_dial.py): packer knob from the environment + a_lo mask of m bits
     "alo0": ["-DDM_WLO_TRUNC_ENV"], "alo3": ["-DDM_WLO_TRUNC_ENV", "-DDM16S_ALO_TRUNC=3"], "alo5": ["-DDM_WLO_TRUNC_ENV", "-DDM16S_ALO_TRUNC=5"],
     "alo6": ["-DDM_WLO_TRUNC_ENV", "-DDM16S_ALO_TRUNC=6"],
+    "roles_dma_m": ["-DDM_WITH_F16X3_ROLES", "-DDM16R_DMA_M"],
     "roles": ["-DDM_WITH_F16X3_ROLES"],                        # round 4: the wave-pair experiment kernel (tools/experiments/f16r, tools/roles_ab.py)
     "trace": ["-DDM_TRACE"],                                   # f16x3 kernel: per-wave timeline of one stage
     "w4": ["-DDM16_WAVES=4", "-DDM16_MT=2"],                   # f16x3 kernel: 4 waves x 2 M-tiles (one wave per SIMD)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): everything profiles/<round>/ cites, into gpurun_out/<round>/.   bash tools/round_evidence.sh r03
-RND=${1:-r03}
+# Run on the GPU box (via gpurun): everything profiles/<round>/ cites, into gpurun_out/<round>/.   bash tools/round_evidence.sh r04
+RND=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$RND
 mkdir -p $O
@@ -13,22 +13,11 @@ for P in f16x3 f16i8 f32; do
   python tools/summarize_profiles.py ${RND}_$P $O/prof_$P > /dev/null
 done
 DM_N=20000 python tools/i8_check.py > $O/i8_check.txt 2>&1
-tools/ubench/mfma_i8 > $O/ubench_mfma_i8.txt 2>&1
 ( python tools/e2e_rate.py packed 200 | sed -n 2,2p; python tools/e2e_rate.py raw 200 | sed -n 2,2p; python tools/e2e_rate.py feat 60 | sed -n 2,2p;
   echo "-- the per-read Python path (DEEPMOD_ROWS_IN_C=0) on the same box:";
   DEEPMOD_ROWS_IN_C=0 python tools/e2e_rate.py packed 200 | sed -n 2,2p; DEEPMOD_ROWS_IN_C=0 python tools/e2e_rate.py raw 200 | sed -n 2,2p ) > $O/e2e_rate.txt 2>&1
-python tools/e2e_detect_raw.py 20000 4,4,6,8 > $O/e2e_detect_raw.txt 2>&1
-python tools/e2e_detect_packed.py 1,2,3,4 > $O/e2e_packed_feeders.txt 2>&1
-python tools/e2e_detect_packed.py 2,3,4 120 > $O/e2e_packed_120x.txt 2>&1
+python tools/e2e_detect_raw.py 20000 4,6 > $O/e2e_detect_raw.txt 2>&1
+python tools/e2e_detect_packed.py 2,2 > $O/e2e_packed_feeders.txt 2>&1
+python tools/e2e_detect_packed.py 2 120 > $O/e2e_packed_120x.txt 2>&1
 for P in f16x3 f16i8 f32; do bash tools/power_trace.sh $O/power_$P.txt python tools/bench_loop.py $P 6 > /dev/null; done
-# energy per launch of timing-only builds of the default kernel (tools/ablate.py build base,s_nocell,s_nodma,s_nobar,s_prod2,s_b64,s_floor)
-: > $O/power_ablations.txt
-for V in base s_nodma s_nocell s_b64 s_nobar s_prod2 s_floor; do
-  [ -f tools/_abl/lib_$V.so ] || continue
-  echo "== $V" >> $O/power_ablations.txt
-  DM_LIB=tools/_abl/lib_$V.so bash tools/power_trace.sh $O/p_$V.txt python tools/bench_loop.py f16x3 5 2>/dev/null | grep -E "launches|socket power|sclk" >> $O/power_ablations.txt
-  rm -f $O/p_$V.txt
-done
-echo "== f16i8 (product library)" >> $O/power_ablations.txt
-bash tools/power_trace.sh $O/p_i8.txt python tools/bench_loop.py f16i8 5 2>/dev/null | grep -E "launches|socket power|sclk" >> $O/power_ablations.txt; rm -f $O/p_i8.txt
-tail -c 400 $O/bench_f16x3.json; echo; cat $O/e2e_rate.txt; cat $O/power_ablations.txt
+tail -c 400 $O/bench_f16x3.json; echo; cat $O/e2e_rate.txt

@@ -556,7 +556,28 @@ def main():
     kernel_ms, launches, kwindows = m.profile_get()
     total_windows = BATCH * args.steps * world
     value = total_windows / elapsed
-
+    # N > 1, after the timed region: what `value` cannot show - the ranks feeding their GPUs from HOST memory at the same time (pageable
+    # x[65536,21,7] in, prob + cls out, synchronous: 588 B in + 9 B out per window over PCIe, all ranks at once; never `value`).  A curve
+    # that bends here and not in `value` is the host side of the node (PCIe / memory bandwidth), not the GPUs
+    host_fed = None
+    if control is not None:
+        err = None                                    # (every rank reaches every barrier / max below whatever its own calls do)
+        try:
+            m.set_option(_lib.DM_OPT_ASYNC, 0)
+            m.predict_windows(x0)
+        except Exception as exc:
+            err = repr(exc)
+        control.barrier()
+        t0 = time.perf_counter()
+        try:
+            for _ in range(3):
+                m.predict_windows(x0)
+        except Exception as exc:
+            err = repr(exc)
+        dt = time.perf_counter() - t0
+        slowest = control.max(dt)
+        host_fed = {"value": world * 3 * BATCH / slowest, "unit": "base-positions/s", "this_rank_windows_per_s": 3 * BATCH / dt, "error_on_this_rank": err,
+                    "note": "all ranks at once, dm_predict_windows on pageable host buffers (PCIe-inclusive), 3 calls of 65,536 windows per rank after the timed region; never `value`"}
     if rank == 0:
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = (kwindows / max(launches, 1)) * FLOP_PER_WINDOW / avg_launch_s / 1e12
@@ -591,12 +612,12 @@ def main():
             out["multi_gpu"] = dict(communicator.stats(), collective="ncclReduceScatter(int32 sum) x 3 counter arrays via dm_summary_reduce_scatter "
                                     "on one persistent dm_comm: rank r is left with the merged counters of positions [r, r + 1) * ceil(L / N)",
                                     reduce_bytes_per_rank=12 * CONTIG_LEN, per_rank=per_rank,
-                                    measured_on_hardware_with_more_than_one_rank=bool(world > 1),
+                                    measured_on_hardware_with_more_than_one_rank=bool(world > 1), host_fed_all_ranks=host_fed,
                                     note="`collectives` / `bytes` count one untimed warm-up merge of the same size and the timed one")
         elif control is not None:
             out["multi_gpu"] = {"collective": "NOT RUN: RCCL could not be set up, the final merge of the counters was skipped (barriers and the "
                                               "max over ranks went through the rendezvous files); the data path has no collective, so `value` stands",
-                                "rccl_error": comm_error, "per_rank": per_rank, "measured_on_hardware_with_more_than_one_rank": bool(world > 1 and os.environ.get("DM_BENCH_ONE_DEVICE") != "1")}
+                                "rccl_error": comm_error, "per_rank": per_rank, "host_fed_all_ranks": host_fed, "measured_on_hardware_with_more_than_one_rank": bool(world > 1 and os.environ.get("DM_BENCH_ONE_DEVICE") != "1")}
         if world == 1 and not args.no_extras:
             out["extras"] = extras(m, _lib, model, args.precision, x_dev[0], x0, prob_dev, cls_dev)
             if not args.no_e2e and args.precision == "f16x3":

@@ -37,6 +37,7 @@ VARIANTS = {
     # round 4: the operand-toggle dial (tools/lo_trunc_dial.py): packer knob from the environment + a_lo mask of m bits
     "alo0": ["-DDM_WLO_TRUNC_ENV"], "alo3": ["-DDM_WLO_TRUNC_ENV", "-DDM16S_ALO_TRUNC=3"], "alo5": ["-DDM_WLO_TRUNC_ENV", "-DDM16S_ALO_TRUNC=5"],
     "alo6": ["-DDM_WLO_TRUNC_ENV", "-DDM16S_ALO_TRUNC=6"],
+    "s_mfma16": ["-DDM16S_ABL_MFMA16"], "s_mfma16_pad": ["-DDM16S_ABL_MFMA16", "-DDM16S_ABL_MFMA16_PAD"],                         # round 4: timing-only, every 32x32x16 MFMA as two 16x16x32 (same MACs, half the accumulator registers per FLOP)
     "roles_dma_m": ["-DDM_WITH_F16X3_ROLES", "-DDM16R_DMA_M"],
     "roles": ["-DDM_WITH_F16X3_ROLES"],                        # round 4: the wave-pair experiment kernel (tools/experiments/f16r, tools/roles_ab.py)
     "trace": ["-DDM_TRACE"],                                   # f16x3 kernel: per-wave timeline of one stage

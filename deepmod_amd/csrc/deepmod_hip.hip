@@ -19,6 +19,7 @@
 #include "head.hip.inc"
 #include "lstm_f32.hip.inc"
 #include "lstm_f16s.hip.inc"
+#include "lstm_f16q.hip.inc"
 #ifdef DM_WITH_F16X3_ROLES   // the matrix / cell wave-pair form of the default kernel (round 4): an experiment build, not part of the product
 #include "../../tools/experiments/f16r/lstm_f16r.hip.inc"
 #endif
@@ -154,6 +155,71 @@ int choose_len_shift(const float* flat) {
 }
 
 
+// 16x16x32 packing (lstm_f16q.hip.inc): [dir][layer][super-tile S][k32-step t][row half][hi|lo][lane][8 x f16].
+// A-operand lane l of a 16-row tile: row m = l % 16 -> unit 8S + 4 rh + m / 4, gate m % 4; k = (g = l / 16, j = 0..7) -> K slot of the B operand:
+//   t < 3 : own unit 8 (4t + j/2) + 4 (j%2) + g
+//   t == 3: j = 0: own unit 96 + g; j = 1: g = 0: the bias row (against the constant 1.0), else zero; j = 2: layer 0: feature g, layers 1, 2: input
+//           unit 96 + g; j = 3: layer 0: feature 4 + g (g = 3: the event length x 2^-len_shift), layers 1, 2: zero; j >= 4: zero
+//   t > 3 : input unit 8 (4 (t-4) + j/2) + 4 (j%2) + g
+Packed16 pack_weights_q(const float* flat) {
+    using namespace lstm16q;
+    Packed16 P;
+    P.w.assign(WEIGHT_BYTES, 0);
+    P.len_shift = choose_len_shift(flat);
+    const float len_mul = std::ldexp(1.0f, P.len_shift);
+    const float* p = flat;
+    for (int d = 0; d < 2; ++d) {
+        size_t off = size_t(d) * WEIGHT_BYTES_DIR;
+        for (int l = 0; l < 3; ++l) {
+            const int kin = l == 0 ? NFEAT : HID;
+            const int nks = l == 0 ? KS_L0 : KS_L12;
+            const float* kern = p;
+            const float* bias = p + size_t(kin + HID) * 400;
+            p += size_t(kin + HID) * 400 + 400;
+            for (int S = 0; S < NTILE; ++S)
+                for (int t = 0; t < nks; ++t) {
+                    _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + off);
+                    off += REC_BYTES;
+                    for (int rh = 0; rh < 2; ++rh)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int m = lane & 15, g = lane >> 4;
+                            const int unit = 8 * S + 4 * rh + m / 4, gate = m % 4;
+                            for (int j = 0; j < 8; ++j) {
+                                float v = 0.0f;
+                                if (unit < HID) {
+                                    const int gc = gate * 100 + unit;
+                                    int krow = -1;          // row of the TF kernel; -2 = bias row; -1 = zero
+                                    float mul = 1.0f;
+                                    if (t < 3) krow = kin + 8 * (4 * t + j / 2) + 4 * (j % 2) + g;
+                                    else if (t == 3) {
+                                        if (j == 0) krow = kin + 96 + g;
+                                        else if (j == 1) krow = g == 0 ? -2 : -1;
+                                        else if (j == 2) krow = l == 0 ? g : 96 + g;
+                                        else if (j == 3 && l == 0) {
+                                            if (g < 3) krow = 4 + g;
+                                            else {
+                                                krow = NFEAT - 1;
+                                                mul = len_mul;
+                                            }
+                                        }
+                                    } else krow = 8 * (4 * (t - 4) + j / 2) + 4 * (j % 2) + g;
+                                    if (krow >= 0) v = kern[size_t(krow) * 400 + gc] * gate_scale(gc) * mul;
+                                    else if (krow == -2) v = (bias[gc] + (gate == 2 ? 1.0f : 0.0f)) * gate_scale(gc);
+                                }
+                                if (!std::isfinite(v)) P.finite = false;
+                                else P.max_abs = std::max(P.max_abs, std::fabs(v));
+                                const _Float16 hi = (_Float16)v;
+                                const _Float16 lo = (_Float16)(v - (float)hi);
+                                dst[((size_t(rh) * 2 + 0) * 64 + lane) * 8 + j] = hi;
+                                dst[((size_t(rh) * 2 + 1) * 64 + lane) * 8 + j] = lo;
+                            }
+                        }
+                }
+        }
+    }
+    return P;
+}
+
 // tile-major split-f16 packing (lstm_f16s.hip.inc): [dir][layer][tile][k16-step][hi|lo][lane][8 x f16].
 // A-operand lane l of record (tile T, k16-step t): gate row m = l % 32 -> unit 8T + m / 4, gate m % 4;
 // k = (half = l / 32, j = 0..7) -> K slot of the B operand the kernel builds in registers:
@@ -168,6 +234,9 @@ int choose_len_shift(const float* flat) {
 // count of the int32 accumulator is i8s = sw 2^-12 / 127^2 pre-activation units for both slots.  Layer 0's mixed k16-step
 // (t = 6: own units 96..99, bias slot, RAW features) keeps its f16 lo record: the kernel runs it with three f16 products.
 // (An int32 accumulator cannot overflow: 2 * 208 slots * 127 * 127 < 2^23.)
+#ifndef DM_F16X3_SHAPE_DEFAULT
+#define DM_F16X3_SHAPE_DEFAULT 16
+#endif
 #ifndef DM_WLO_TRUNC_DEFAULT
 #define DM_WLO_TRUNC_DEFAULT 0
 #endif
@@ -415,6 +484,8 @@ struct dm_model {
     float* d_bpack = nullptr;
     float* d_hpack = nullptr;
     unsigned char* d_wpack16s = nullptr;  // split-f16 weights in the tile-major layout (DM_PREC_F16X3)
+    unsigned char* d_wpack16q = nullptr;  // the same weights in the 16x16x32 layout (lstm_f16q.hip.inc)
+    bool f16_q = false;                   // DM_PREC_F16X3 runs lstm16q::bilstm_f16q_kernel (16x16x32 MFMAs) instead of lstm16s::bilstm_f16s_kernel<0>
     unsigned char* d_wpack16i = nullptr;  // the same layout with int8 cross-term records (DM_PREC_F16I8)
     float i8s[24] = {};                   // its fold scales [dir][layer][gate kind]
     float* d_wout = nullptr;              // head W[200][2] fp32 (DM_PREC_F16X3)
@@ -546,6 +617,18 @@ int ensure_f16s(dm_model* m) {
     return DM_OK;
 }
 
+int ensure_f16q(dm_model* m) {
+    if (m->d_wpack16q) return DM_OK;
+    int rc = ensure_f16_common(m);
+    if (rc) return rc;
+    Packed16 P = pack_weights_q(m->host_weights.data());
+    HIP_TRY(hipMalloc(&m->d_wpack16q, P.w.size()));
+    HIP_TRY(hipMemcpy(m->d_wpack16q, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16q::bilstm_f16q_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16q::LDS_BYTES)));
+    return DM_OK;
+}
+
 int ensure_f16i8(dm_model* m) {
     if (m->d_wpack16i) return DM_OK;
     int rc = ensure_f16_common(m);
@@ -583,7 +666,8 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
     if (m->precision == DM_PREC_F16X3 || m->precision == DM_PREC_F16I8 || m->precision == DM_PREC_F16X3_ROLES) {
         using namespace lstm16s;
         const bool i8 = m->precision == DM_PREC_F16I8;
-        int rc = i8 ? ensure_f16i8(m) : ensure_f16s(m);
+        const bool q16 = m->precision == DM_PREC_F16X3 && m->f16_q;
+        int rc = i8 ? ensure_f16i8(m) : (q16 ? ensure_f16q(m) : ensure_f16s(m));
         if (rc) return rc;
         Params p;
         p.wpack = m->d_wpack16s;
@@ -603,7 +687,10 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         p.len_scale = std::ldexp(1.0f, -m->len_shift);
         p.range_flag = m->d_range_flag + m->range_cur;
         const int grid = std::min(2 * p.ntiles, m->grid_cap);
-        if (i8) hipLaunchKernelGGL(bilstm_f16s_kernel<1>, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
+        if (q16) {
+            p.wpack = m->d_wpack16q;
+            hipLaunchKernelGGL(lstm16q::bilstm_f16q_kernel, dim3(grid), dim3(lstm16q::THREADS), lstm16q::LDS_BYTES, m->stream, p);
+        } else if (i8) hipLaunchKernelGGL(bilstm_f16s_kernel<1>, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
 #ifdef DM_WITH_F16X3_ROLES
         else if (m->precision == DM_PREC_F16X3_ROLES) hipLaunchKernelGGL(lstm16r::bilstm_f16r_kernel, dim3(grid), dim3(lstm16r::THREADS_R), lstm16r::LDS_BYTES_R, m->stream, p);
 #endif
@@ -808,6 +895,11 @@ int model_init(dm_model* m, const float* weights) {
         m->len_shift = P16.len_shift;
         m->precision = m->f16_ok ? DM_PREC_F16X3 : DM_PREC_F32;
     }
+    {   // which kernel runs DM_PREC_F16X3: lstm_f16q.hip.inc (16x16x32 MFMAs; default since round 4: 1.2-2.6 % less time per launch, profiles/r04/shape_ab.txt)
+        // or, with DM_F16X3_SHAPE=32 in the environment at model creation, lstm_f16s.hip.inc (32x32x16: rounds 2-3; also the int8 mode's kernel)
+        const char* e = std::getenv("DM_F16X3_SHAPE");
+        m->f16_q = e && *e ? std::atoi(e) == 16 : DM_F16X3_SHAPE_DEFAULT == 16;
+    }
     return DM_OK;
 }
 
@@ -876,6 +968,7 @@ void dm_model_destroy(dm_model* m) {
     (void)hipFree(m->d_hpack);
     (void)hipFree(m->d_scratch);
     (void)hipFree(m->d_wpack16s);
+    (void)hipFree(m->d_wpack16q);
     (void)hipFree(m->d_wpack16i);
     (void)hipFree(m->d_wout);
     (void)hipFree(m->d_dbg);

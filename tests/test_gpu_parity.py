@@ -348,6 +348,12 @@ def test_wave_pair_experiment_kernel_is_refused_or_bit_identical(gpu_device):
             m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3_ROLES)
         assert m.get_info(_lib.DM_INFO_PRECISION) == _lib.DM_PREC_F16X3
     else:
+        m.close()
+        os.environ["DM_F16X3_SHAPE"] = "32"          # the experiment kernel is the 32x32x16 kernel's arithmetic, bit for bit
+        try:
+            m = model.BiLSTMModel(w, device=gpu_device)
+        finally:
+            del os.environ["DM_F16X3_SHAPE"]
         for n in (1, 129, 4097, 70000):
             x = synth.synthetic_windows(n, seed=12 + n)
             m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3)
@@ -488,3 +494,29 @@ def test_int8_mode_is_selected_per_model_by_the_calibration_gate(gpu_device):
     m = model.BiLSTMModel(trained_like_weights(), device=gpu_device, precision="f32")
     assert m.calibrate_i8()[1] is False and m.get_info(_lib.DM_INFO_PRECISION) == _lib.DM_PREC_F32
     m.close()
+
+
+def test_both_mfma_shapes_behind_the_default_precision(gpu_device):
+    """DM_PREC_F16X3 runs lstm16q::bilstm_f16q_kernel (16x16x32 MFMAs, default since round 4) or, with DM_F16X3_SHAPE=32 at model creation,
+    lstm16s::bilstm_f16s_kernel<0> (32x32x16, rounds 2-3): the same three-product arithmetic in a different summation order - both inside the
+    path's tolerance against the oracle with an order of magnitude to spare, on ragged sizes, three weight sets and out-of-range event lengths."""
+    def make(w, shape):
+        os.environ["DM_F16X3_SHAPE"] = str(shape)
+        try:
+            return model.BiLSTMModel(w, device=gpu_device)
+        finally:
+            del os.environ["DM_F16X3_SHAPE"]
+    for w in (synth.synthetic_weights(21, 1.0), synth.synthetic_weights(26, 4.0), trained_like_weights()):
+        m16, m32 = make(w, 16), make(w, 32)
+        for n in (1, 15, 16, 17, 31, 32, 33, 127, 129, 4097, 20000):
+            x = synth.synthetic_windows(n, seed=300 + n)
+            if n == 4097:
+                x[::7, :, 6] = 3.0e6                      # event lengths beyond the f16 range: the rescaled slot of lane group 3
+            ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
+            p16, c16 = m16.predict_windows(x)
+            p32, c32 = m32.predict_windows(x)
+            assert _check(p16, c16, ref_prob, ref_cls) <= 3e-5
+            assert _check(p32, c32, ref_prob, ref_cls) <= 3e-5
+            assert np.abs(p16 - p32).max() <= 3e-5
+        m16.close()
+        m32.close()

@@ -13,6 +13,9 @@ for P in f16x3 f16i8 f32; do
   python tools/summarize_profiles.py ${RND}_$P $O/prof_$P > /dev/null
 done
 DM_N=20000 python tools/i8_check.py > $O/i8_check.txt 2>&1
+python tools/shape_ab.py > $O/shape_ab.txt 2>&1
+python tools/i8_tail.py > $O/i8_tail.txt 2>&1
+for S in 32 16 32 16; do echo "== DM_F16X3_SHAPE=$S"; DM_F16X3_SHAPE=$S bash tools/power_trace.sh $O/p_shape.txt python tools/bench_loop.py f16x3 5 2>/dev/null | grep -E "launches|socket power|sclk"; done > $O/power_shapes.txt 2>&1; rm -f $O/p_shape.txt
 ( python tools/e2e_rate.py packed 200 | sed -n 2,2p; python tools/e2e_rate.py raw 200 | sed -n 2,2p; python tools/e2e_rate.py feat 60 | sed -n 2,2p;
   echo "-- the per-read Python path (DEEPMOD_ROWS_IN_C=0) on the same box:";
   DEEPMOD_ROWS_IN_C=0 python tools/e2e_rate.py packed 200 | sed -n 2,2p; DEEPMOD_ROWS_IN_C=0 python tools/e2e_rate.py raw 200 | sed -n 2,2p ) > $O/e2e_rate.txt 2>&1

@@ -19,6 +19,7 @@ DM_OPT_PROFILE = 1
 DM_OPT_PRECISION = 2
 DM_OPT_ASYNC = 3
 DM_OPT_RESERVED_CUS = 4
+DM_OPT_F16X3_SHAPE = 5   # 16 (default: 16x16x32 MFMAs) | 32 (the 32x32x16 kernel of rounds 2-3)
 DM_PREC_F32 = 0
 DM_PREC_F16X3 = 1
 DM_PREC_F16I8 = 3      # opt-in, reduced precision: int8 cross terms (2 issued matrix units per product instead of 3; worst window of 1e6 1.1e-4 instead of 9e-6 at weight scale 4)

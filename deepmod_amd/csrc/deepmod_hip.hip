@@ -994,6 +994,10 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
         case DM_OPT_ASYNC:
             m->async = value != 0;
             return DM_OK;
+        case DM_OPT_F16X3_SHAPE:
+            if (value != 16 && value != 32) return fail(DM_EINVAL, "DM_OPT_F16X3_SHAPE: %lld (16 or 32)", (long long)value);
+            m->f16_q = value == 16;
+            return DM_OK;
         case DM_OPT_RESERVED_CUS:
             if (value < 0 || value > m->num_cu / 2) return fail(DM_EINVAL, "reserved CUs %lld outside [0, %d]", (long long)value, m->num_cu / 2);
             m->grid_cap = m->num_cu - int(value);

@@ -60,13 +60,16 @@ extern "C" {
 #define DM_OPT_RESERVED_CUS 4 /* n in [0, CUs / 2]: the classifier's persistent grid uses CUs - n workgroups (one per CU), so that
                               small kernels of OTHER streams (the signal stage of the streaming worker) run beside a classifier
                               launch instead of waiting for it to drain.  Default 0. */
+#define DM_OPT_F16X3_SHAPE 5  /* which build of the DM_PREC_F16X3 kernel runs: 16 (default: v_mfma_f32_16x16x32_f16, lstm_f16q.hip.inc) or 32
+                              (v_mfma_f32_32x32x16_f16, lstm_f16s.hip.inc: rounds 2-3; 1-3 % slower on full launches, ~2 % faster on
+                              launches that leave most of the chip idle).  Same arithmetic, another summation order: results differ
+                              in the last bits.  The environment variable DM_F16X3_SHAPE sets the initial value at dm_model_create. */
 #define DM_PREC_F32 0      /* fp32 MFMA (v_mfma_f32_16x16x4_f32): fp32 products, the TF graph's own arithmetic */
 #define DM_PREC_F16X3 1    /* split-f16 MFMA: every fp32 operand = hi + lo f16, 3 products per fp32 product, fp32
                               accumulation; max |dp| vs the oracle 1e-6 .. 2e-6 (tolerance of the path: 1e-4), ~3x faster.
                               Step-major kernel: weights and feature rows in, logits out, the state of the three layers never
                               leaves the chip.  Two builds of it: csrc/lstm_f16q.hip.inc on v_mfma_f32_16x16x32_f16 (the one that
-                              runs since round 4) and csrc/lstm_f16s.hip.inc on v_mfma_f32_32x32x16_f16 (DM_F16X3_SHAPE=32 in the
-                              environment when the model is created; 1-3 % slower; same arithmetic, another summation order).
+                              runs since round 4) and csrc/lstm_f16s.hip.inc on v_mfma_f32_32x32x16_f16 (DM_OPT_F16X3_SHAPE).
                               Range contract (nothing is clamped silently):
                                 * weights: every kernel / bias value times its exponent scale (<= 2.886) must be a finite f16
                                   (|w| <~ 22,700).  A model that violates this is created with DM_PREC_F32 as its default and

@@ -348,12 +348,7 @@ def test_wave_pair_experiment_kernel_is_refused_or_bit_identical(gpu_device):
             m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3_ROLES)
         assert m.get_info(_lib.DM_INFO_PRECISION) == _lib.DM_PREC_F16X3
     else:
-        m.close()
-        os.environ["DM_F16X3_SHAPE"] = "32"          # the experiment kernel is the 32x32x16 kernel's arithmetic, bit for bit
-        try:
-            m = model.BiLSTMModel(w, device=gpu_device)
-        finally:
-            del os.environ["DM_F16X3_SHAPE"]
+        m.set_option(_lib.DM_OPT_F16X3_SHAPE, 32)          # the experiment kernel is the 32x32x16 kernel's arithmetic, bit for bit
         for n in (1, 129, 4097, 70000):
             x = synth.synthetic_windows(n, seed=12 + n)
             m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3)
@@ -500,12 +495,16 @@ def test_both_mfma_shapes_behind_the_default_precision(gpu_device):
     """DM_PREC_F16X3 runs lstm16q::bilstm_f16q_kernel (16x16x32 MFMAs, default since round 4) or, with DM_F16X3_SHAPE=32 at model creation,
     lstm16s::bilstm_f16s_kernel<0> (32x32x16, rounds 2-3): the same three-product arithmetic in a different summation order - both inside the
     path's tolerance against the oracle with an order of magnitude to spare, on ragged sizes, three weight sets and out-of-range event lengths."""
+    from deepmod_amd import _lib
+
     def make(w, shape):
-        os.environ["DM_F16X3_SHAPE"] = str(shape)
-        try:
-            return model.BiLSTMModel(w, device=gpu_device)
-        finally:
-            del os.environ["DM_F16X3_SHAPE"]
+        m = model.BiLSTMModel(w, device=gpu_device)
+        m.set_option(_lib.DM_OPT_F16X3_SHAPE, shape)
+        return m
+    m = make(synth.synthetic_weights(21, 1.0), 16)
+    with pytest.raises(_lib.DeepModHipError):
+        m.set_option(_lib.DM_OPT_F16X3_SHAPE, 8)
+    m.close()
     for w in (synth.synthetic_weights(21, 1.0), synth.synthetic_weights(26, 4.0), trained_like_weights()):
         m16, m32 = make(w, 16), make(w, 32)
         for n in (1, 15, 16, 17, 31, 32, 33, 127, 129, 4097, 20000):

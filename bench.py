@@ -409,8 +409,11 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=sorted(PRECISIONS), default="f16x3",
-                    help="MFMA mode of the classifier kernel (f16x3 and f32 meet the 1e-4 probability tolerance; f16i8 is the opt-in reduced-precision mode)")
+    ap.add_argument("--precision", choices=sorted(PRECISIONS) + ["auto"], default="f16x3",
+                    help="MFMA mode of the classifier kernel (f16x3 and f32 meet the 1e-4 probability tolerance; f16i8 is the reduced-precision mode; "
+                         "auto = what the command line does: f16x3 unless the model's own calibration run lets f16i8 in)")
+    ap.add_argument("--weights", choices=["synthetic", "trained-like"], default="synthetic",
+                    help="synthetic: U(-a, a) kernels at scale 4 (seed 26; the workload of every round); trained-like: tests/golden/trained_like_weights.npz")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (other precision, host-buffer rate, e2e)")
     ap.add_argument("--no-e2e", action="store_true", help="skip extras.e2e (configs[2] through bin/DeepMod.py detect: ~6 GB of synthetic input in /dev/shm or /tmp)")
     args = ap.parse_args()
@@ -461,8 +464,15 @@ def main():
         communicator, comm_error = _agree(rdv, "comm_up", communicator, comm_error)
         control = communicator if communicator is not None else _FileControl(rdv)
 
-    weights = synth.synthetic_weights(seed=26, scale=4.0)     # ~50 % of the windows are class 1: both summary branches are taken
+    if args.weights == "trained-like":
+        z = np.load(os.path.join(ROOT, "tests", "golden", "trained_like_weights.npz"))
+        weights = {k.replace("|", "/"): np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
+    else:
+        weights = synth.synthetic_weights(seed=26, scale=4.0)     # ~50 % of the windows are class 1: both summary branches are taken
     m = model.BiLSTMModel(weights, device=device, precision=args.precision)
+    calibration = m.calibration
+    if args.precision == "auto":          # the line is labelled with the mode the gate chose
+        args.precision = {_lib.DM_PREC_F16X3: "f16x3", _lib.DM_PREC_F16I8: "f16i8", _lib.DM_PREC_F32: "f32"}[m.get_info(_lib.DM_INFO_PRECISION)]
     m.set_option(_lib.DM_OPT_PROFILE, 1)
     P = PRECISIONS[args.precision]
 
@@ -596,7 +606,7 @@ def main():
                                    "synthetic weights (real .data shards absent), %d windows/step resident in HBM, "
                                    "%d distinct batches (1,048,576 windows)" % (BATCH, n_batches),
                        "batch": BATCH, "windows_total": total_windows, "parallelism": "window-sharded x%d" % world, "forced_dist_dry_run": bool(dist_mode and world == 1), "all_ranks_on_device_0_test_hook": os.environ.get("DM_BENCH_ONE_DEVICE") == "1", "setup_launches": SETUP_LAUNCHES,
-                       "precision": P["label"]},
+                       "precision": P["label"], "weights": args.weights, "calibration_gate": calibration},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": P["peak"], "unit": "TFLOP/s",
                          "frac": achieved / P["peak"], "traffic": (traffic or {}).get("bytes"),
                          "traffic_detail": traffic, "algorithmic_bytes": 596 * BATCH,

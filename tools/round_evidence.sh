@@ -7,6 +7,7 @@ mkdir -p $O
 python bench.py > $O/bench_f16x3.json 2> $O/bench_f16x3.err
 python bench.py --precision f16i8 --no-cpu-baseline --no-extras > $O/bench_f16i8.json 2>/dev/null
 python bench.py --precision f32 --no-cpu-baseline --no-extras > $O/bench_f32.json 2>/dev/null
+python bench.py --weights trained-like --precision auto > $O/bench_trained_like_auto.json 2>/dev/null
 DM_BENCH_FORCE_DIST=1 MASTER_PORT=29999 python bench.py --steps 8 --no-cpu-baseline --no-extras > $O/bench_forced_dist.json 2> $O/bench_forced_dist.err
 for P in f16x3 f16i8 f32; do
   bash tools/profile_round.sh ${RND}_$P $P >> $O/profile.log 2>&1

@@ -309,3 +309,28 @@ def test_feeder_budget_of_a_streaming_run():
     assert feeder_budget(1, 1, 2, False) == (1, 1, None)
     assert feeder_budget(2, 8, 16, False) == (1, 1, None)            # fewer threads than ranks: still one per rank
     assert feeder_budget(8, 1, 1, False) == (8, 1, None)             # never below one
+
+
+def test_gpu_count_from_the_kernel_drivers_topology_files(tmp_path, monkeypatch):
+    """bin/DeepMod.py kfd_gpu_count: with --gpus N the command asks the KFD topology, not a HIP runtime of its own (0.14 s of a 1.8 s run):
+    gfx950 nodes that can be read count, CPU nodes and nodes hidden by the device cgroup do not, the *_VISIBLE_DEVICES lists cap the answer,
+    an unreadable topology is None (the caller then asks the runtime)."""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location('dmcli', os.path.join(ROOT, 'bin', 'DeepMod.py'))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(var, raising=False)
+    assert cli.kfd_gpu_count(str(tmp_path / 'missing')) is None
+    base = tmp_path / 'nodes'
+    for i, props in enumerate(("simd_count 0\ngfx_target_version 0\n", "simd_count 1024\ngfx_target_version 90500\n", None,
+                               "simd_count 1024\ngfx_target_version 90500\n", "simd_count 1216\ngfx_target_version 90402\n")):
+        os.makedirs(base / str(i))
+        if props is not None:                 # node 2: no readable properties file (what a device cgroup leaves of a GPU that is not ours)
+            (base / str(i) / 'properties').write_text(props)
+    assert cli.kfd_gpu_count(str(base)) == 2
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0')
+    assert cli.kfd_gpu_count(str(base)) == 1
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1,2')
+    assert cli.kfd_gpu_count(str(base)) == 2

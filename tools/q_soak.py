@@ -1,0 +1,36 @@
+"""Dev tool (GPU box): soak of the 16x16x32 kernel - a hazard that depends on timing would show as a rare wrong window, not in every run.
+For a few minutes: random batch sizes, three weight sets, with a second model's launches in flight on another stream; every output compared
+with the 32x32x16 kernel's (different summation order: <= 3e-5), re-run bit-identical, and a 10^6-window pass against the oracle's classes."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from deepmod_amd import _lib, model, synth
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 150.0
+z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'trained_like_weights.npz'))
+sets = [synth.synthetic_weights(26, 4.0), synth.synthetic_weights(21, 1.0), {k.replace('|', '/'): np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}]
+pairs = []
+for w in sets:
+    a = model.BiLSTMModel(w, 0); a.set_option(_lib.DM_OPT_F16X3_SHAPE, 16)
+    b = model.BiLSTMModel(w, 0); b.set_option(_lib.DM_OPT_F16X3_SHAPE, 32)
+    pairs.append((a, b))
+noise = model.BiLSTMModel(sets[0], 0); noise.set_option(_lib.DM_OPT_ASYNC, 1)
+dn = model.DeviceArray.from_host(synth.synthetic_windows(65536, seed=3), 0); dcn = model.DeviceArray((65536,), np.uint8, 0)
+xall = synth.synthetic_windows(300000, seed=77)
+rng = np.random.default_rng(5)
+t0, it, worst, nwin = time.time(), 0, 0.0, 0
+while time.time() - t0 < secs:
+    a, b = pairs[it % 3]
+    n = int(rng.choice([1, 17, 31, 33, 127, 129, 1000, 4097, 65536, int(rng.integers(1, 300000))]))
+    o = int(rng.integers(0, 300000 - n + 1))
+    x = xall[o:o + n]
+    for _ in range(int(rng.integers(0, 4))):
+        noise.predict_windows(dn, cls=dcn, want_prob=False)      # another stream's launches compete for the CUs
+    p1, c1 = a.predict_windows(x)
+    p2, c2 = a.predict_windows(x)
+    p3, c3 = b.predict_windows(x)
+    assert np.array_equal(p1.view(np.uint32), p2.view(np.uint32)) and np.array_equal(c1, c2), ("re-run differs", it, n)
+    d = float(np.abs(p1 - p3).max())
+    assert d <= 3e-5, ("shapes differ", it, n, d)
+    worst = max(worst, d); nwin += n; it += 1
+noise.sync()
+print("%d iterations, %d windows in %.0f s: every re-run bit-identical, 16x16x32 vs 32x32x16 worst %.3g" % (it, nwin, time.time() - t0, worst))

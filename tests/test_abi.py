@@ -36,3 +36,17 @@ def test_flatten_matches_oracle_blob():
     w = synth.synthetic_weights(1, 1.0)
     assert np.array_equal(model.flatten_weights(w), oracle_np.flatten_weights(w))
     assert model.flatten_weights(w).size == _lib.DM_WEIGHT_FLOATS
+
+
+def test_header_constants_equal_the_bindings():
+    """Every DM_OPT_* / DM_PREC_* / DM_INFO_* / error code the header defines has the same value in deepmod_amd/_lib.py (a constant that
+    drifts between the two would select another kernel or misread an error without any symbol going missing)."""
+    text = open(os.path.join(ROOT, "include", "deepmod_hip.h")).read()
+    defines = {n: int(v) for n, v in re.findall(r"^#define\s+(DM_(?:OPT|PREC|INFO|OK|E[A-Z]+|MAP|ROWS)[A-Z0-9_]*)\s+\(?(-?\d+)\)?", text, flags=re.M)}
+    assert {"DM_OPT_PRECISION", "DM_OPT_F16X3_SHAPE", "DM_PREC_F16X3", "DM_PREC_F16I8", "DM_PREC_F16X3_ROLES", "DM_INFO_HAS_F16X3_ROLES", "DM_ERANGE"} <= set(defines)
+    checked = 0
+    for name, value in defines.items():
+        if hasattr(_lib, name):
+            assert getattr(_lib, name) == value, name
+            checked += 1
+    assert checked >= 20

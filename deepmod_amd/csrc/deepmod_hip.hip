@@ -155,12 +155,14 @@ int choose_len_shift(const float* flat) {
 }
 
 
-// 16x16x32 packing (lstm_f16q.hip.inc): [dir][layer][super-tile S][k32-step t][row half][hi|lo][lane][8 x f16].
-// A-operand lane l of a 16-row tile: row m = l % 16 -> unit 8S + 4 rh + m / 4, gate m % 4; k = (g = l / 16, j = 0..7) -> K slot of the B operand:
-//   t < 3 : own unit 8 (4t + j/2) + 4 (j%2) + g
-//   t == 3: j = 0: own unit 96 + g; j = 1: g = 0: the bias row (against the constant 1.0), else zero; j = 2: layer 0: feature g, layers 1, 2: input
-//           unit 96 + g; j = 3: layer 0: feature 4 + g (g = 3: the event length x 2^-len_shift), layers 1, 2: zero; j >= 4: zero
-//   t > 3 : input unit 8 (4 (t-4) + j/2) + 4 (j%2) + g
+// 16x16x32 packing (lstm_f16q.hip.inc): [dir][layer][super-tile S][records in the kernel's processing order].
+// A-operand lane l of a 16-row tile: row m = l % 16 -> unit 8S + 4 rh + m / 4, gate m % 4; k = (g = l / 16, j = 0..7) -> K slot of the B operand.
+//   own t = 0..2 / input t = 0..2 (layers 1, 2), 4 KB each, [row half][hi|lo][lane][8 x f16]: slot j = own / input unit 8 (4t + j/2) + 4 (j%2) + g
+//   mixed, 2 KB, [row half][lane][8 x f16] - the three products of the left-over slots side by side (round 5):
+//       j = 0, 1, 2: (hi, lo, hi) of the weight of own unit 96 + g      against the B slots (h_hi, h_hi, h_lo)
+//       j = 3, 4, 5: (hi, lo, hi) of the weight of input unit 96 + g (layer 0: of feature g) against (x_hi, x_hi, x_lo)
+//       j = 6, 7   : g = 0: (hi, lo) of the bias row against (1, 1); else zero
+//   layer 0 only, a second mixed record: j = 0, 1, 2: (hi, lo, hi) of the weight of feature 4 + g (g = 3: the event length x 2^len_shift), j >= 3: zero
 Packed16 pack_weights_q(const float* flat) {
     using namespace lstm16q;
     Packed16 P;
@@ -168,53 +170,75 @@ Packed16 pack_weights_q(const float* flat) {
     P.len_shift = choose_len_shift(flat);
     const float len_mul = std::ldexp(1.0f, P.len_shift);
     const float* p = flat;
+    auto split = [&](float v, _Float16& hi, _Float16& lo) {
+        if (!std::isfinite(v)) P.finite = false;
+        else P.max_abs = std::max(P.max_abs, std::fabs(v));
+        hi = (_Float16)v;
+        lo = (_Float16)(v - (float)hi);
+    };
     for (int d = 0; d < 2; ++d) {
         size_t off = size_t(d) * WEIGHT_BYTES_DIR;
         for (int l = 0; l < 3; ++l) {
             const int kin = l == 0 ? NFEAT : HID;
-            const int nks = l == 0 ? KS_L0 : KS_L12;
             const float* kern = p;
             const float* bias = p + size_t(kin + HID) * 400;
             p += size_t(kin + HID) * 400 + 400;
-            for (int S = 0; S < NTILE; ++S)
-                for (int t = 0; t < nks; ++t) {
+            // weight of TF kernel row krow (-2: the bias row, -1: nothing) for gate column gc, exponent scale folded
+            auto wval = [&](int krow, int gc, float mul) {
+                if (krow >= 0) return kern[size_t(krow) * 400 + gc] * gate_scale(gc) * mul;
+                if (krow == -2) return (bias[gc] + (gc >= 200 && gc < 300 ? 1.0f : 0.0f)) * gate_scale(gc);
+                return 0.0f;
+            };
+            for (int S = 0; S < NTILE; ++S) {
+                // ordinary records: own 0..2, then (layers 1, 2) input 0..2
+                for (int rec = 0; rec < (l == 0 ? 3 : 6); ++rec) {
                     _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + off);
                     off += REC_BYTES;
+                    const bool is_own = rec < 3;
+                    const int t = is_own ? rec : rec - 3;
                     for (int rh = 0; rh < 2; ++rh)
                         for (int lane = 0; lane < 64; ++lane) {
                             const int m = lane & 15, g = lane >> 4;
                             const int unit = 8 * S + 4 * rh + m / 4, gate = m % 4;
                             for (int j = 0; j < 8; ++j) {
-                                float v = 0.0f;
-                                if (unit < HID) {
-                                    const int gc = gate * 100 + unit;
-                                    int krow = -1;          // row of the TF kernel; -2 = bias row; -1 = zero
-                                    float mul = 1.0f;
-                                    if (t < 3) krow = kin + 8 * (4 * t + j / 2) + 4 * (j % 2) + g;
-                                    else if (t == 3) {
-                                        if (j == 0) krow = kin + 96 + g;
-                                        else if (j == 1) krow = g == 0 ? -2 : -1;
-                                        else if (j == 2) krow = l == 0 ? g : 96 + g;
-                                        else if (j == 3 && l == 0) {
-                                            if (g < 3) krow = 4 + g;
-                                            else {
-                                                krow = NFEAT - 1;
-                                                mul = len_mul;
-                                            }
-                                        }
-                                    } else krow = 8 * (4 * (t - 4) + j / 2) + 4 * (j % 2) + g;
-                                    if (krow >= 0) v = kern[size_t(krow) * 400 + gc] * gate_scale(gc) * mul;
-                                    else if (krow == -2) v = (bias[gc] + (gate == 2 ? 1.0f : 0.0f)) * gate_scale(gc);
-                                }
-                                if (!std::isfinite(v)) P.finite = false;
-                                else P.max_abs = std::max(P.max_abs, std::fabs(v));
-                                const _Float16 hi = (_Float16)v;
-                                const _Float16 lo = (_Float16)(v - (float)hi);
+                                _Float16 hi = (_Float16)0.0f, lo = (_Float16)0.0f;
+                                if (unit < HID) split(wval((is_own ? kin : 0) + 8 * (4 * t + j / 2) + 4 * (j % 2) + g, gate * 100 + unit, 1.0f), hi, lo);
                                 dst[((size_t(rh) * 2 + 0) * 64 + lane) * 8 + j] = hi;
                                 dst[((size_t(rh) * 2 + 1) * 64 + lane) * 8 + j] = lo;
                             }
                         }
                 }
+                // mixed record(s)
+                for (int mrec = 0; mrec < (l == 0 ? 2 : 1); ++mrec) {
+                    _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + off);
+                    off += MIX_BYTES;
+                    for (int rh = 0; rh < 2; ++rh)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int m = lane & 15, g = lane >> 4;
+                            const int unit = 8 * S + 4 * rh + m / 4, gate = m % 4;
+                            _Float16 slot[8];
+                            for (int j = 0; j < 8; ++j) slot[j] = (_Float16)0.0f;
+                            if (unit < HID) {
+                                const int gc = gate * 100 + unit;
+                                _Float16 hi, lo;
+                                if (mrec == 0) {
+                                    split(wval(kin + 96 + g, gc, 1.0f), hi, lo);
+                                    slot[0] = hi; slot[1] = lo; slot[2] = hi;
+                                    split(wval(l == 0 ? g : 96 + g, gc, 1.0f), hi, lo);
+                                    slot[3] = hi; slot[4] = lo; slot[5] = hi;
+                                    if (g == 0) {
+                                        split(wval(-2, gc, 1.0f), hi, lo);
+                                        slot[6] = hi; slot[7] = lo;
+                                    }
+                                } else {
+                                    split(g < 3 ? wval(4 + g, gc, 1.0f) : wval(NFEAT - 1, gc, len_mul), hi, lo);
+                                    slot[0] = hi; slot[1] = lo; slot[2] = hi;
+                                }
+                            }
+                            for (int j = 0; j < 8; ++j) dst[(size_t(rh) * 64 + lane) * 8 + j] = slot[j];
+                        }
+                }
+            }
         }
     }
     return P;

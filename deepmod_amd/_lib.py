@@ -41,7 +41,9 @@ _i64 = ctypes.c_int64
 SIGNATURES = [
     ("dm_last_error", _c.c_char_p, []),
     ("dm_version", _c.c_char_p, []),
+    ("dm_build_flags", _c.c_char_p, []),
     ("dm_device_count", _c.c_int, []),
+    ("dm_device_pci_bus_id", _c.c_int, [_c.c_int, _c.c_char_p, _c.c_int]),
     ("dm_model_create", _vp, [_c.c_int, _vp, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     ("dm_model_destroy", None, [_vp]),
     ("dm_model_set_option", _c.c_int, [_vp, _c.c_int, _i64]),
@@ -143,6 +145,12 @@ def check(rc: int) -> None:
         err = DeepModHipError(msg)
         err.code = rc
         raise err
+
+
+def pci_bus_id(device: int) -> str:
+    buf = ctypes.create_string_buffer(64)
+    check(load().dm_device_pci_bus_id(device, buf, 64))
+    return buf.value.decode()
 
 
 def last_error() -> str:

@@ -2,6 +2,26 @@
 // Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
 
+// ---- experiment switches (round 5: one umbrella) ------------------------------------------------------------------------------------------
+// Every macro below turns a product kernel into a TIMING-ONLY or otherwise experimental build (tools/ablate.py).  None of them may reach
+// the product by accident: without -DDM_EXPERIMENT any of them is a compile error, and dm_build_flags() reports what a library was built with
+// (tests/test_build_guard.py checks the shipped library says "experiment=0").
+#if defined(DM16Q_ABL_NOCELL) || defined(DM16Q_ABL_NODMA) || defined(DM16Q_ABL_MIX1) || defined(DM16Q_AINIT) || defined(DM16Q_DEBUG_NOP) ||           \
+    defined(DM16Q_NOCHUNK) || defined(DM16Q_NOPN) || defined(DM16Q_PRE) || defined(DM16Q_SNAKE) || defined(DM16Q_TRANS_COST) ||                     \
+    defined(DM16S_ABL_2PROD) || defined(DM16S_ABL_B64) || defined(DM16S_ABL_LO_ONLY) || defined(DM16S_ABL_MFMA16) ||                              \
+    defined(DM16S_ABL_MFMA16_PAD) || defined(DM16S_ABL_NOBAR) || defined(DM16S_ABL_NOCELL) || defined(DM16S_ABL_NODMA) ||                          \
+    defined(DM16S_ABL_NOLDSA) || defined(DM16S_ADIST) || defined(DM16S_ALO_TRUNC) || defined(DM16S_PRE) || defined(DM_ABL_NOBAR) ||                \
+    defined(DM_ABL_NODMA) || defined(DM_ABL_NOEPI) || defined(DM_ABL_NOSEQ) || defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2) ||   \
+    defined(DM_WLO_TRUNC_ENV) || defined(DM_WLO_TRUNC_DEFAULT) || defined(DM_WITH_F16X3_ROLES) || defined(DM16R_DMA_M) ||                         \
+    defined(DM_F16X3_SHAPE_DEFAULT) || defined(DM_WAVES) || defined(DM_MT)
+#define DM_ANY_EXPERIMENT_SWITCH 1
+#ifndef DM_EXPERIMENT
+#error "an ablation / experiment macro is defined without -DDM_EXPERIMENT: timing-only kernels must not be built into the product by a stray -D"
+#endif
+#else
+#define DM_ANY_EXPERIMENT_SWITCH 0
+#endif
+
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -935,7 +955,23 @@ int model_init(dm_model* m, const float* weights) {
 extern "C" {
 
 const char* dm_last_error(void) { return g_err.c_str(); }
-const char* dm_version(void) { return "deepmod_hip 0.1 (gfx950)"; }
+#define DM_STR2(X) #X
+#define DM_STR(X) DM_STR2(X)
+// the compiler is part of the identity of the hand-scheduled kernels: the evidence of a round is valid for the hipcc it was taken with
+const char* dm_version(void) { return "deepmod_hip 0.5 (gfx950; hip " DM_STR(HIP_VERSION_MAJOR) "." DM_STR(HIP_VERSION_MINOR) "." DM_STR(HIP_VERSION_PATCH) "; " __VERSION__ ")"; }
+const char* dm_build_flags(void) {
+#ifdef DM_EXPERIMENT
+    return "experiment=1 switches=" DM_STR(DM_ANY_EXPERIMENT_SWITCH);
+#else
+    return "experiment=0 switches=0";
+#endif
+}
+
+int dm_device_pci_bus_id(int device, char* buf, int len) {
+    if (!buf || len < 13) return fail(DM_EINVAL, "dm_device_pci_bus_id: buffer of >= 13 bytes");
+    HIP_TRY(hipDeviceGetPCIBusId(buf, len, device));
+    return DM_OK;
+}
 
 int dm_device_count(void) {
     int n = 0;

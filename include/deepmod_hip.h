@@ -106,8 +106,16 @@ typedef struct dm_summary dm_summary;
 const char* dm_last_error(void);
 const char* dm_version(void);
 
+/* "experiment=0 switches=0" for the product; "experiment=1 ..." for a library built with -DDM_EXPERIMENT (tools/ablate.py: timing-only
+ * kernels).  Any ablation macro without -DDM_EXPERIMENT is a compile error.  dm_version() also names the HIP / clang version the
+ * library was compiled with (the hand-scheduled kernels are validated per compiler).  No reference counterpart. */
+const char* dm_build_flags(void);
+
 /* number of visible gfx950 devices (0 if none / HIP unusable) */
 int dm_device_count(void);
+/* PCI bus id ("0000:05:00.0") of HIP device `device` into buf (>= 13 bytes): the key under /sys/bus/pci/devices/ where the driver
+ * publishes the device's socket power and clocks (deepmod_amd/powerlog.py, bench.py roofline.power).  No reference counterpart. */
+int dm_device_pci_bus_id(int device, char* buf, int len);
 
 /*
  * Build a model on `device` from the canonical flat weight blob (DM_WEIGHT_FLOATS floats, host):

@@ -62,7 +62,7 @@ def build(names):
     for name in names:
         out = os.path.join(ABL, "lib_%s.so" % name)
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-mllvm", "-amdgpu-mfma-vgpr-form", "-o", out, src,
-               "-ldl"] + VARIANTS[name]
+               "-ldl"] + VARIANTS[name] + (["-DDM_EXPERIMENT"] if VARIANTS[name] else [])      # any switch needs the umbrella (deepmod_hip.hip: a stray -D is a compile error)
         subprocess.check_call(cmd, cwd=os.path.dirname(src))
         print("built", out)
 

@@ -182,7 +182,8 @@ int choose_len_shift(const float* flat) {
 //       j = 0, 1, 2: (hi, lo, hi) of the weight of own unit 96 + g      against the B slots (h_hi, h_hi, h_lo)
 //       j = 3, 4, 5: (hi, lo, hi) of the weight of input unit 96 + g (layer 0: of feature g) against (x_hi, x_hi, x_lo)
 //       j = 6, 7   : g = 0: (hi, lo) of the bias row against (1, 1); else zero
-//   layer 0 only, a second mixed record: j = 0, 1, 2: (hi, lo, hi) of the weight of feature 4 + g (g = 3: the event length x 2^len_shift), j >= 3: zero
+//   layer 0 only, a second mixed record: j = 0, 1, 2, 3: (hi, lo, hi, lo) of the weight of feature 4 + g (g = 3: the event length x 2^len_shift)
+//       against (x_hi, x_hi, x_lo, x_lo) - all FOUR products of the signal features (event lengths reach 10^4); j >= 4: zero
 Packed16 pack_weights_q(const float* flat) {
     using namespace lstm16q;
     Packed16 P;
@@ -252,7 +253,7 @@ Packed16 pack_weights_q(const float* flat) {
                                     }
                                 } else {
                                     split(g < 3 ? wval(4 + g, gc, 1.0f) : wval(NFEAT - 1, gc, len_mul), hi, lo);
-                                    slot[0] = hi; slot[1] = lo; slot[2] = hi;
+                                    slot[0] = hi; slot[1] = lo; slot[2] = hi; slot[3] = lo;      // j = 3: x_lo w_lo, the fourth product (free slot)
                                 }
                             }
                             for (int j = 0; j < 8; ++j) dst[(size_t(rh) * 64 + lane) * 8 + j] = slot[j];
@@ -729,6 +730,7 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         if (rcp) return rcp;
         p.plogit = m->d_plogit;
         p.len_scale = std::ldexp(1.0f, -m->len_shift);
+        p.len_mul = std::ldexp(1.0f, m->len_shift);
         p.range_flag = m->d_range_flag + m->range_cur;
         const int grid = std::min(2 * p.ntiles, m->grid_cap);
         if (q16) {
@@ -942,7 +944,12 @@ int model_init(dm_model* m, const float* weights) {
     {   // which kernel runs DM_PREC_F16X3: lstm_f16q.hip.inc (16x16x32 MFMAs; default since round 4: 1.2-2.6 % less time per launch, profiles/r04/shape_ab.txt)
         // or, with DM_F16X3_SHAPE=32 in the environment at model creation, lstm_f16s.hip.inc (32x32x16: rounds 2-3; also the int8 mode's kernel)
         const char* e = std::getenv("DM_F16X3_SHAPE");
-        m->f16_q = e && *e ? std::atoi(e) == 16 : DM_F16X3_SHAPE_DEFAULT == 16;
+        m->f16_q = DM_F16X3_SHAPE_DEFAULT == 16;
+        if (e && *e) {
+            if (!std::strcmp(e, "16")) m->f16_q = true;
+            else if (!std::strcmp(e, "32")) m->f16_q = false;
+            else std::fprintf(stderr, "deepmod_hip: DM_F16X3_SHAPE=%s ignored (16 or 32); the default shape %d stays\n", e, DM_F16X3_SHAPE_DEFAULT);
+        }
     }
     return DM_OK;
 }
@@ -1180,8 +1187,11 @@ __device__ __forceinline__ uint64_t mix(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-__device__ __forceinline__ float unit(uint64_t h) { return (float)((h >> 40) + 1) * (1.0f / 16777217.0f); }      // (0, 1)
-__global__ void windows_kernel(float* __restrict__ x, long long n_rows, uint64_t seed) {
+__device__ __forceinline__ float unit(uint64_t h) { return ((float)(h >> 41) + 0.5f) * (1.0f / 8388608.0f); }      // (0, 1): 23 bits + 1/2, exact in fp32
+// wide = 0: the configs[1] distribution.  wide = 1 (every second batch, round 5): READ-SHAPED tails the nominal draw hardly ever produces - event
+// means uniform over the whole clip range with 6 % exactly on the clip (+-5: the MAD-normalised signal is clipped there), standard deviations
+// up to 9x, event lengths log-uniform from 1 to 30,000 samples (stalled events) - so that the gate sees the inputs a real run can feed
+__global__ void windows_kernel(float* __restrict__ x, long long n_rows, uint64_t seed, int wide) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     const uint64_t h0 = mix(seed * 0x100000001B3ull + (uint64_t)i * 4u), h1 = mix(h0), h2 = mix(h1), h3 = mix(h2);
@@ -1195,6 +1205,13 @@ __global__ void windows_kernel(float* __restrict__ x, long long n_rows, uint64_t
     r[4] = rintf(fminf(fmaxf(1.2f * z0, -5.0f), 5.0f) * 1000.0f) * 0.001f;
     r[5] = rintf(fabsf(0.25f + 0.15f * z1) * 1000.0f) * 0.001f;
     r[6] = 1.0f + floorf(logf(unit(h3)) * (1.0f / -0.12783337f));      // ln(1 - 0.12)
+    if (wide) {
+        const uint64_t h4 = mix(h3), h5 = mix(h4);
+        const float u = unit(h4), v = unit(h5);
+        r[4] = u < 0.03f ? -5.0f : (u > 0.97f ? 5.0f : rintf((10.0f * unit(h1) - 5.0f) * 1000.0f) * 0.001f);
+        r[5] = rintf(fabsf(0.25f + 0.15f * z1) * (1.0f + 8.0f * v * v) * 1000.0f) * 0.001f;
+        r[6] = floorf(exp2f(unit(h3) * 14.8727f));                     // 1 .. 30,000
+    }
 }
 // largest |a - b| of two probability arrays (non-negative floats order like their bit patterns)
 __global__ void maxdiff_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, unsigned* __restrict__ out) {
@@ -1242,7 +1259,7 @@ int dm_model_calibrate_i8(dm_model* m, int64_t n_windows, double bound, double* 
     for (int64_t done = 0, batch = 0; done < n_windows && rc == DM_OK; done += B, ++batch) {
         const int64_t n = std::min<int64_t>(B, n_windows - done);
         const long long rows = (long long)n * DM_WINDOW;
-        hipLaunchKernelGGL(calib::windows_kernel, dim3(unsigned((rows + 255) / 256)), dim3(256), 0, m->stream, d_x, rows, uint64_t(0x5EEDC0DEull + batch));
+        hipLaunchKernelGGL(calib::windows_kernel, dim3(unsigned((rows + 255) / 256)), dim3(256), 0, m->stream, d_x, rows, uint64_t(0x5EEDC0DEull + batch), int(batch & 1));
         m->precision = DM_PREC_F32;
         rc = launch_bilstm(m, d_x, (long long)DM_WINDOW * DM_NFEAT, n, d_pa, nullptr);
         m->precision = DM_PREC_F16I8;
@@ -1262,9 +1279,11 @@ int dm_model_calibrate_i8(dm_model* m, int64_t n_windows, double bound, double* 
     float err;
     std::memcpy(&err, &bits, 4);
     if (max_abs_dp) *max_abs_dp = double(err);
-    if (double(err) <= bound) {
-        if (m->precision == DM_PREC_F16X3) m->precision = DM_PREC_F16I8;
-        if (selected) *selected = m->precision == DM_PREC_F16I8 ? 1 : 0;
+    if (double(err) <= bound && m->precision == DM_PREC_F16X3) m->precision = DM_PREC_F16I8;
+    if (selected) *selected = m->precision == DM_PREC_F16I8 ? 1 : 0;      // the mode the model runs after the call
+    if (m->precision != DM_PREC_F16I8 && m->d_wpack16i) {                    // a refused model does not keep the int8 weight pack (1.7 MB)
+        (void)hipFree(m->d_wpack16i);
+        m->d_wpack16i = nullptr;
     }
     return DM_OK;
 }

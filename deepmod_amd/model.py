@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -289,13 +290,23 @@ class Session:
         self.device = device
         self.model: Optional[BiLSTMModel] = None
 
-    # the command-line path (every model the detect command loads comes through here): DM_PREC_F16X3 unless the model's own calibration
-    # lets the int8 mode in (BiLSTMModel.calibrate_i8); DEEPMOD_PRECISION = f16x3 / f32 / f16i8 / auto overrides
+    # the command-line path (every model the detect command loads comes through here): DM_PREC_F16X3, the mode that meets the path's 1e-4
+    # tolerance by construction (round 5: the int8 cross-term mode is opt-in again - its documented bound is 2e-4).  DEEPMOD_PRECISION =
+    # f32 / f16i8 overrides; DEEPMOD_PRECISION=auto lets the model's own calibration run decide between f16x3 and f16i8
+    # (BiLSTMModel.calibrate_i8) and says on stderr what it chose
+    def _load(self, tensors):
+        want = os.environ.get("DEEPMOD_PRECISION", "f16x3")
+        self.model = BiLSTMModel(tensors, self.device, precision=want)
+        if want == "auto" and self.model.calibration is not None:
+            c = self.model.calibration
+            sys.stderr.write("deepmod_amd: DEEPMOD_PRECISION=auto: calibration max|dp| %.3g on %d windows (bound %.3g) -> %s\n"
+                             % (c["max_abs_dp"], c["windows"], c["bound"], "f16i8 (int8 cross terms)" if c["selected_f16i8"] else "f16x3"))
+
     def restore(self, prefix: str):
-        self.model = BiLSTMModel(tfbundle.load_bundle(prefix), self.device, precision=os.environ.get("DEEPMOD_PRECISION", "auto"))
+        self._load(tfbundle.load_bundle(prefix))
 
     def load_tensors(self, tensors: Dict[str, np.ndarray]):
-        self.model = BiLSTMModel(tensors, self.device, precision=os.environ.get("DEEPMOD_PRECISION", "auto"))
+        self._load(tensors)
 
     def run(self, fetches, feed_dict=None):
         single = not isinstance(fetches, (list, tuple))

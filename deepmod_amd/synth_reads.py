@@ -22,7 +22,10 @@ def synthetic_genome(length: int, seed: int = 1) -> str:
 
 
 def synthetic_read(rng, genome: str, chrom: str, readk: str, min_len=2000, max_len=10000,
-                   p_sub=0.06, p_ins=0.02, p_del=0.02, max_clip=20) -> Dict:
+                   p_sub=0.06, p_ins=0.02, p_del=0.02, max_clip=20, p_tail=0.0) -> Dict:
+    """p_tail > 0: that fraction of the events gets READ-SHAPED extremes a nominal draw hardly produces - a normalised mean anywhere in
+    the clip range with a third of them exactly on the clip (+-5, myDetect.py's clipped MAD normalisation) and a length log-uniform
+    between 50 and 30,000 samples (stalled events).  p_tail = 0 draws exactly what earlier rounds drew (same random stream)."""
     strand = '+' if rng.random() < 0.5 else '-'
     span = int(rng.integers(min_len, max_len + 1))
     start = int(rng.integers(0, len(genome) - span - 1))
@@ -60,6 +63,12 @@ def synthetic_read(rng, genome: str, chrom: str, readk: str, min_len=2000, max_l
     mean = np.round(np.clip(rng.normal(mu, 0.3), -5, 5), 3)
     stdv = np.round(np.abs(rng.normal(0.25, 0.15, n_ev)), 3)
     length = rng.geometric(0.12, n_ev)
+    if p_tail > 0:
+        tail = rng.random(n_ev) < p_tail
+        kind = rng.random(n_ev)
+        wide = np.round(rng.uniform(-5, 5, n_ev), 3)
+        mean = np.where(tail, np.where(kind < 1 / 6, -5.0, np.where(kind < 1 / 3, 5.0, wide)), mean)
+        length = np.where(tail, np.exp(rng.uniform(np.log(50.0), np.log(30000.0), n_ev)).astype(np.int64), length)
     events = predstore.events_from_bases(bases, mean, stdv, length)
     nins = int((refb == '-').sum())
     ndel = int((readb == '-').sum())

@@ -92,7 +92,8 @@ extern "C" {
                               graph, 2 windows exceed the path's 1e-4 tolerance and 99.99 % are below 6.5e-5 (DM_PREC_F16X3: worst
                               9e-6); at weight scale 1: 6e-6.  Documented bound 2e-4; classes equal wherever p1 is further than that
                               from 0.5.  Same range contract as DM_PREC_F16X3 (the raw features never ride the int8 product).
-                              Never selected by default; per model through dm_model_calibrate_i8 below. */
+                              Never selected by default - neither by the library nor by the command line; opt-in per model through
+                              dm_model_calibrate_i8 below (the command line: DEEPMOD_PRECISION=auto). */
 /* dm_model_get_info keys */
 #define DM_INFO_PRECISION 1          /* DM_PREC_* in effect */
 #define DM_INFO_F16_REPRESENTABLE 2  /* 1 if the weights fit DM_PREC_F16X3 */
@@ -130,12 +131,14 @@ int dm_model_set_option(dm_model* m, int key, int64_t value);
 int dm_model_get_info(dm_model* m, int key, int64_t* value);
 /*
  * Load-time calibration gate of the opt-in int8 mode (round 4; no reference counterpart - the reference runs fp32 TensorFlow kernels,
- * myMultiBiRNN.py:38-61).  Classifies n_windows synthetic windows of the BASELINE configs[1] distribution (generated on the device,
- * the same on every box) with DM_PREC_F32 and with DM_PREC_F16I8 and reports the largest |p(f32) - p(f16i8)| in *max_abs_dp.  If that
- * is <= bound and the model currently runs DM_PREC_F16X3, DM_PREC_F16I8 becomes its precision (*selected = 1); otherwise nothing
- * changes (*selected = 0).  What the mode's error is depends on the weights: 1.2e-5 in the tail of 10^6 windows for weights with
- * trained statistics, 7e-5 - 1.1e-4 for U(-a, a) kernels at scale 4 (profiles/r04/i8_tail.txt) - hence a gate per model, never a
- * global default.  10^6 windows take ~0.12 s.  Synchronises the model's stream.
+ * myMultiBiRNN.py:38-61).  Classifies n_windows synthetic windows generated on the device (the same on every box; alternating batches
+ * of 65,536: the BASELINE configs[1] distribution, and - round 5 - a read-shaped tail draw: event means over the whole +-5 clip range
+ * with 6 % exactly on the clip, standard deviations up to 9x, event lengths log-uniform 1 .. 30,000 samples) with DM_PREC_F32 and with
+ * DM_PREC_F16I8 and reports the largest |p(f32) - p(f16i8)| in *max_abs_dp.  If that is <= bound and the model currently runs
+ * DM_PREC_F16X3, DM_PREC_F16I8 becomes its precision.  *selected = 1 if the model runs DM_PREC_F16I8 after the call (also when it
+ * already did), else 0; a model that does not run it afterwards does not keep the int8 weight pack.  What the mode's error is depends
+ * on the weights: 1.2e-5 in the tail of 10^6 windows for weights with trained statistics, 7e-5 - 1.1e-4 for U(-a, a) kernels at scale 4
+ * (profiles/r04/i8_tail.txt) - hence a gate per model, never a global default.  10^6 windows take ~0.12 s.  Synchronises the model's stream.
  */
 int dm_model_calibrate_i8(dm_model* m, int64_t n_windows, double bound, double* max_abs_dp, int* selected);
 

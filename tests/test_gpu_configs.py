@@ -90,3 +90,42 @@ def test_config1_exact_generator_and_site_level_auc(tmp_path, gpu_device):
         sel = sites['cov'] >= 5
         fpr, tpr, _ = roc_curve(np.isin(sites['pos'], truth)[sel], sites['pct'][sel])
         assert abs(auc(fpr, tpr) - auc_ref[5]) < 1e-12
+
+
+def test_trained_like_model_through_the_command_default_and_auto(tmp_path, gpu_device):
+    """the only model with TRAINED weight statistics in the tree (tests/golden/trained_like_weights.npz) as a model
+    directory through `bin/DeepMod.py detect`, on reads with read-shaped extremes (3 % of the events: normalised means anywhere in the clip
+    range incl. exactly +-5, lengths up to 30,000 samples) - once with the command's defaults (DM_PREC_F16X3) and once with
+    DEEPMOD_PRECISION=auto, where the load-time gate lets the int8 cross-term mode in for THIS model.  Both BED files of both runs equal
+    the oracle pipeline's (reference myDetect.py:787-834, :1089-1120) byte for byte: the smallest |p1 - 0.5| of the read set is 2.0e-4,
+    so a mode that moved any probability by 1e-4 could still not be told from one that flipped a class - the int8 mode's per-window error
+    on the same rows is held to 1e-4 in test_gpu_parity.py::test_selected_mode_on_read_shaped_rows."""
+    from conftest import trained_like_weights
+    from deepmod_amd import tfbundle
+    w = trained_like_weights()
+    prefix = str(tmp_path / 'model' / 'mod_train_trained_like')
+    os.makedirs(os.path.dirname(prefix))
+    tfbundle.write_bundle(prefix, w, layout=synth.REAL_LAYOUT, total_size=synth.REAL_DATA_SIZE)
+    wrk = tmp_path / 'reads'
+    files = synth_reads.write_synthetic_run(str(wrk), n_reads=24, reads_per_file=4, genome_len=25000, seed=33, chrom='chrT', min_len=400,
+                                            max_len=1600, p_tail=0.03)
+    want, margin, nwin = oracle_beds(files, w, 'C')
+    assert margin > 1e-4 and nwin > 20000, (margin, nwin)          # 2.03e-4 on this read set
+    out = str(tmp_path / 'out')
+    assert os.environ.get('DEEPMOD_PRECISION') is None
+    stdout = _detect(wrk, prefix, out, 'dflt', 'C')
+    assert 'Streaming detect: 24 reads' in stdout
+    os.environ['DEEPMOD_PRECISION'] = 'auto'
+    try:
+        cmd = [sys.executable, os.path.join(ROOT, 'bin', 'DeepMod.py'), 'detect', '--wrkBase', str(wrk), '--modfile', prefix, '--outFolder', out,
+               '--FileID', 'auto', '--threads', '2', '--Base', 'C', '--gpus', '1']
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    finally:
+        os.environ.pop('DEEPMOD_PRECISION', None)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    assert 'DEEPMOD_PRECISION=auto' in res.stderr and '-> f16i8' in res.stderr, res.stderr[-2000:]      # the gate let the int8 mode in, and said so
+    for (chrom, strand), bed in want.items():
+        assert len(bed) > 100000
+        for fid in ('dflt', 'auto'):
+            got = open('%s/%s/mod_pos.%s%s.C.bed' % (out, fid, chrom, strand), 'rb').read()
+            assert got == bed, (fid, strand)

@@ -519,3 +519,39 @@ def test_both_mfma_shapes_behind_the_default_precision(gpu_device):
             assert np.abs(p16 - p32).max() <= 3e-5
         m16.close()
         m32.close()
+
+
+def test_selected_mode_on_read_shaped_rows(gpu_device):
+    """the mode DEEPMOD_PRECISION=auto selects for the trained-like model (the load-time gate -> int8 cross terms) on
+    READ-SHAPED rows - per-read feature matrices of synthetic reads with 5 % tail events (normalised means over the whole clip range,
+    a third exactly +-5; event lengths up to 30,000 samples), windows assembled on the device (dm_predict_read) - against the C oracle at
+    the PATH's tolerance 1e-4, not the mode's own 2e-4; and the default mode on the same rows (fp32-class).  Reference: myDetect.py:787-834."""
+    from conftest import trained_like_weights
+    from deepmod_amd import synth_reads
+    w = trained_like_weights()
+    m_auto = model.BiLSTMModel(w, device=gpu_device, precision="auto")
+    assert m_auto.calibration["selected_f16i8"], m_auto.calibration
+    m_dflt = model.BiLSTMModel(w, device=gpu_device)
+    m_f32 = model.BiLSTMModel(w, device=gpu_device, precision="f32")
+    genome = synth_reads.synthetic_genome(30000, 5)
+    rng = np.random.default_rng(77)
+    worst = {"auto": 0.0, "default": 0.0, "f32": 0.0}
+    n_tail = 0
+    for i in range(12):
+        rd = synth_reads.synthetic_read(rng, genome, 'chrT', 'r%d' % i, min_len=600, max_len=2500, p_tail=0.05)
+        rows = np.ascontiguousarray(rd['mfeatures'][:, 3:], np.float32)
+        n = rows.shape[0] - 200
+        n_tail += int((np.abs(rows[100:-100, 4]) == 5.0).sum() + (rows[100:-100, 6] > 1000).sum())
+        xw = np.stack([rows[100 + j - 10:100 + j + 11] for j in range(n)])
+        ref_prob, ref_cls = oracle_np.predict_windows_c(w, xw)
+        near = np.abs(ref_prob[:, 1] - 0.5) < 1e-4
+        for name, mm in (("auto", m_auto), ("default", m_dflt), ("f32", m_f32)):
+            prob, cls = mm.predict_read(rows, 100, n)
+            worst[name] = max(worst[name], float(np.abs(prob - ref_prob).max()))
+            assert not ((cls.astype(np.int64) != ref_cls) & ~near).any(), (name, i)
+    assert n_tail > 300                                          # the tail events are really there
+    assert worst["auto"] <= 1e-4, worst                          # the path's tolerance, with the int8 cross terms
+    # the default mode is fp32-class: on these rows the fp32 kernel itself is ~2e-5 from the oracle (event lengths of 10^4 samples make
+    # pre-activations of 10^2..10^3, whose fp32 round-off depends on the summation order), and the default stays within a few 1e-6 of that
+    assert worst["f32"] <= 5e-5 and worst["default"] <= worst["f32"] + 1e-5, worst
+    m_auto.close(); m_dflt.close(); m_f32.close()

@@ -78,10 +78,11 @@ def kfd_gpu_count(base='/sys/class/kfd/kfd/topology/nodes'):
             continue
         if props.get('gfx_target_version') == '90500' and int(props.get('simd_count', '0')) > 0:
             n += 1
-    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
-        v = os.environ.get(var)
-        if v is not None and v.strip() != '':
-            n = min(n, len([t for t in v.split(',') if t.strip() != '']))
+    # A *_VISIBLE_DEVICES filter changes what the runtime shows in ways the topology files do not tell (ROCR and HIP filters compose, an
+    # invalid or -1 entry truncates the list): with any of them set the runtime is asked instead
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES', 'GPU_DEVICE_ORDINAL'):
+        if os.environ.get(var, '').strip() != '':
+            return None
     return n
 
 

@@ -74,7 +74,15 @@ def rows_from_packed(pk: Dict, base: str, src: str, out: Prepared) -> None:
     meta = pk['reads']
     start_clip = np.array([m['start_clip'] for m in meta], np.int64)
     end_clip = np.array([m['end_clip'] for m in meta], np.int64)
-    n_al = (eo[1:] - eo[:-1]) - start_clip - end_clip                     # aligned events per read
+    # clips come from a container's metadata: classified BEFORE any arithmetic with them (values near the ends of int64 would wrap the
+    # subtraction into a plausible count) - negative: an index error of the ledger; too large for the read: no aligned event = "Less Event"
+    # (the same rule as rowsbatch.inc plan_read: the ledger keys of the two build paths agree)
+    nev = eo[1:] - eo[:-1]
+    clip_neg = (start_clip < 0) | (end_clip < 0)
+    clip_over = ~clip_neg & ((start_clip > nev) | (end_clip > nev - np.minimum(start_clip, nev)))
+    start_clip = np.where(clip_neg | clip_over, 0, start_clip)
+    end_clip = np.where(clip_neg | clip_over, 0, end_clip)
+    n_al = np.where(clip_neg | clip_over, 0, nev - start_clip - end_clip)     # aligned events per read
     readb, refb, refi = pk['readbase'], pk['refbase'], pk['refbasei']
     not_gap = readb != b'-'
     is_base = refb == base.encode('ascii')                                # Base is one of ACGT: never '-', 'N', 'n'
@@ -86,7 +94,9 @@ def rows_from_packed(pk: Dict, base: str, src: str, out: Prepared) -> None:
     n_have = excl[bo[1:]] - first_cnt                                      # aligned table rows per read
     ok = (n_al >= 50) & (n_have >= n_al) & ((ro[1:] - ro[:-1]) == n_al + 2 * PAD)
     for i in np.flatnonzero(~ok):
-        if n_al[i] < 50:
+        if clip_neg[i]:
+            out.errors["Prediction failed: IndexError"].append(src)
+        elif n_al[i] < 50:
             out.errors["Less Event"].append(src)                          # myDetect.py:702-705
         else:
             out.errors["Prediction failed: IndexError"].append(src)       # fewer aligned table rows than aligned events

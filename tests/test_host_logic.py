@@ -313,14 +313,14 @@ def test_feeder_budget_of_a_streaming_run():
 
 def test_gpu_count_from_the_kernel_drivers_topology_files(tmp_path, monkeypatch):
     """bin/DeepMod.py kfd_gpu_count: with --gpus N the command asks the KFD topology, not a HIP runtime of its own (0.14 s of a 1.8 s run):
-    gfx950 nodes that can be read count, CPU nodes and nodes hidden by the device cgroup do not, the *_VISIBLE_DEVICES lists cap the answer,
+    gfx950 nodes that can be read count, CPU nodes and nodes hidden by the device cgroup do not, a *_VISIBLE_DEVICES filter hands the question to the runtime,
     an unreadable topology is None (the caller then asks the runtime)."""
     import importlib.util
     from conftest import ROOT
     spec = importlib.util.spec_from_file_location('dmcli', os.path.join(ROOT, 'bin', 'DeepMod.py'))
     cli = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(cli)
-    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES', 'GPU_DEVICE_ORDINAL'):
         monkeypatch.delenv(var, raising=False)
     assert cli.kfd_gpu_count(str(tmp_path / 'missing')) is None
     base = tmp_path / 'nodes'
@@ -330,7 +330,10 @@ def test_gpu_count_from_the_kernel_drivers_topology_files(tmp_path, monkeypatch)
         if props is not None:                 # node 2: no readable properties file (what a device cgroup leaves of a GPU that is not ours)
             (base / str(i) / 'properties').write_text(props)
     assert cli.kfd_gpu_count(str(base)) == 2
-    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0')
-    assert cli.kfd_gpu_count(str(base)) == 1
-    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1,2')
+    # any *_VISIBLE_DEVICES filter: the topology files cannot say what the runtime will show (filters compose, -1 truncates) -> None,
+    # the caller asks the runtime
+    for var, val in (('HIP_VISIBLE_DEVICES', '0'), ('ROCR_VISIBLE_DEVICES', '0,1,2'), ('CUDA_VISIBLE_DEVICES', '1,-1,0')):
+        monkeypatch.setenv(var, val)
+        assert cli.kfd_gpu_count(str(base)) is None
+        monkeypatch.delenv(var)
     assert cli.kfd_gpu_count(str(base)) == 2

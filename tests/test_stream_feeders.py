@@ -388,4 +388,23 @@ def test_clips_at_the_ends_of_int64_are_a_ledger_line_not_a_wild_read(tmp_path):
         got = stream._prepare_batch_c(dict(mo), [files[0], bad])
         assert got.n_reads == want.n_reads + 2, (clips, got.n_reads, dict(got.errors))
         assert sum(len(v) for v in got.errors.values()) >= 1, clips
+        # the ledger keys are the interface: the compiled and the Python build path file the read under the SAME reason -
+        # negative clips an index error, clips merely too large for the read "Less Event" (n_events - clips < 50, myDetect.py:702-705)
+        py = stream._prepare_batch_py(dict(mo), [files[0], bad])
+        assert {k: sorted(v) for k, v in got.errors.items() if v} == {k: sorted(v) for k, v in py.errors.items() if v}, (clips, dict(got.errors), dict(py.errors))
+        key = "Prediction failed: IndexError" if min(clips) < 0 else "Less Event"
+        assert got.errors.get(key) == [bad], (clips, dict(got.errors))
+        assert py.n_reads == got.n_reads and py.n_rows == got.n_rows
         os.remove(bad)
+    # ordinary out-of-range clips (start_clip = 1000 on a read of a few hundred events): "Less Event" on both paths
+    pk = predstore.load_packed(files[1])
+    z = {k: np.array(pk[k]) for k in ('tx', 'refbase', 'readbase', 'refbasei', 'evbase', 'row_off', 'bmi_off', 'ev_off')}
+    reads = [dict(r) for r in pk['reads']]
+    reads[1]['start_clip'], reads[1]['end_clip'] = 1000, 0
+    z['format'] = np.array(2)
+    z['meta'] = np.array(json.dumps({'reads': reads, 'contig_len': {}}))
+    bad = str(tmp_path / 'in' / ('clips' + predstore.CONTAINER_SUFFIX))
+    with open(bad, 'wb') as fh:
+        npzmap.savez_aligned(fh, **z)
+    for fn in (stream._prepare_batch_c, stream._prepare_batch_py):
+        assert fn(dict(mo), [bad]).errors.get("Less Event") == [bad], fn.__name__

@@ -184,7 +184,11 @@ int choose_len_shift(const float* flat) {
 //       j = 6, 7   : g = 0: (hi, lo) of the bias row against (1, 1); else zero
 //   layer 0 only, a second mixed record: j = 0, 1, 2, 3: (hi, lo, hi, lo) of the weight of feature 4 + g (g = 3: the event length x 2^len_shift)
 //       against (x_hi, x_hi, x_lo, x_lo) - all FOUR products of the signal features (event lengths reach 10^4); j >= 4: zero
-Packed16 pack_weights_q(const float* flat) {
+// int8 = true (DM_PREC_F16I8 on this shape, round 5): the second KB of a row half of an ORDINARY record holds, instead of the lo f16 halves, the int8
+// cross-term weights of the same 32 K slots: bytes (2j, 2j + 1) of lane l = (w_hi8, w_lo8) of the unit of slot j - they meet the B bytes (lo8, hi8) of that
+// unit in one v_mfma_i32_16x16x64_i8.  Scales per (direction, layer, gate kind) exactly as in pack_weights_tile below: sw = max(|w_hi|, 2^12 |w_lo|) over the
+// rows that ride the int8 product (own / input units 0..95), i8s = sw 2^-12 / 127^2.  The mixed records keep their f16 form.
+Packed16 pack_weights_q(const float* flat, const bool int8 = false, float* i8s = nullptr) {
     using namespace lstm16q;
     Packed16 P;
     P.w.assign(WEIGHT_BYTES, 0);
@@ -210,10 +214,27 @@ Packed16 pack_weights_q(const float* flat) {
                 if (krow == -2) return (bias[gc] + (gc >= 200 && gc < 300 ? 1.0f : 0.0f)) * gate_scale(gc);
                 return 0.0f;
             };
+            float sw[4] = {1.f, 1.f, 1.f, 1.f};
+            if (int8) {
+                for (int gk = 0; gk < 4; ++gk) {
+                    float m = 0.0f;
+                    for (int u = 0; u < HID; ++u)
+                        for (int krow = (l == 0 ? kin : 0); krow < kin + 96; ++krow) {
+                            if (l > 0 && krow >= 96 && krow < kin) continue;          // input units 96..99 ride the mixed record
+                            const float v = wval(krow, gk * 100 + u, 1.0f);
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)(v - (float)hi);
+                            m = std::max(m, std::max(std::fabs((float)hi), 4096.0f * std::fabs((float)lo)));
+                        }
+                    sw[gk] = m > 0.0f ? m : 1.0f;
+                    if (i8s) i8s[(d * 3 + l) * 4 + gk] = sw[gk] / (4096.0f * 127.0f * 127.0f);
+                }
+            }
             for (int S = 0; S < NTILE; ++S) {
                 // ordinary records: own 0..2, then (layers 1, 2) input 0..2
                 for (int rec = 0; rec < (l == 0 ? 3 : 6); ++rec) {
                     _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + off);
+                    signed char* dst8 = reinterpret_cast<signed char*>(P.w.data() + off);
                     off += REC_BYTES;
                     const bool is_own = rec < 3;
                     const int t = is_own ? rec : rec - 3;
@@ -225,7 +246,14 @@ Packed16 pack_weights_q(const float* flat) {
                                 _Float16 hi = (_Float16)0.0f, lo = (_Float16)0.0f;
                                 if (unit < HID) split(wval((is_own ? kin : 0) + 8 * (4 * t + j / 2) + 4 * (j % 2) + g, gate * 100 + unit, 1.0f), hi, lo);
                                 dst[((size_t(rh) * 2 + 0) * 64 + lane) * 8 + j] = hi;
-                                dst[((size_t(rh) * 2 + 1) * 64 + lane) * 8 + j] = lo;
+                                if (!int8) dst[((size_t(rh) * 2 + 1) * 64 + lane) * 8 + j] = lo;
+                                else {
+                                    const float s8 = 127.0f / sw[gate];
+                                    const float qh = std::nearbyint((float)hi * s8), ql = std::nearbyint((float)lo * s8 * 4096.0f);
+                                    signed char* d8 = dst8 + (size_t(rh) * 2 + 1) * 1024 + size_t(lane) * 16 + 2 * j;
+                                    d8[0] = (signed char)std::max(-127.0f, std::min(127.0f, qh));
+                                    d8[1] = (signed char)std::max(-127.0f, std::min(127.0f, ql));
+                                }
                             }
                         }
                 }
@@ -533,6 +561,8 @@ struct dm_model {
     bool f16_q = false;                   // DM_PREC_F16X3 runs lstm16q::bilstm_f16q_kernel (16x16x32 MFMAs) instead of lstm16s::bilstm_f16s_kernel<0>
     unsigned char* d_wpack16i = nullptr;  // the same layout with int8 cross-term records (DM_PREC_F16I8)
     float i8s[24] = {};                   // its fold scales [dir][layer][gate kind]
+    unsigned char* d_wpack16qi = nullptr; // DM_PREC_F16I8 in the 16x16x32 layout (lstm16q::bilstm_f16q_kernel<1>: int8 16x16x64 cross terms)
+    float i8s_q[24] = {};                 // its fold scales
     float* d_wout = nullptr;              // head W[200][2] fp32 (DM_PREC_F16X3)
     float* d_scratch = nullptr;
     unsigned long long* d_dbg = nullptr;  // DM_TIMING builds only
@@ -669,8 +699,20 @@ int ensure_f16q(dm_model* m) {
     Packed16 P = pack_weights_q(m->host_weights.data());
     HIP_TRY(hipMalloc(&m->d_wpack16q, P.w.size()));
     HIP_TRY(hipMemcpy(m->d_wpack16q, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16q::bilstm_f16q_kernel),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16q::bilstm_f16q_kernel<0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16q::LDS_BYTES)));
+    return DM_OK;
+}
+
+int ensure_f16qi(dm_model* m) {
+    if (m->d_wpack16qi) return DM_OK;
+    int rc = ensure_f16_common(m);
+    if (rc) return rc;
+    Packed16 P = pack_weights_q(m->host_weights.data(), true, m->i8s_q);
+    HIP_TRY(hipMalloc(&m->d_wpack16qi, P.w.size()));
+    HIP_TRY(hipMemcpy(m->d_wpack16qi, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16q::bilstm_f16q_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16q::LDS_BYTES_I8)));
     return DM_OK;
 }
 
@@ -712,12 +754,13 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         using namespace lstm16s;
         const bool i8 = m->precision == DM_PREC_F16I8;
         const bool q16 = m->precision == DM_PREC_F16X3 && m->f16_q;
-        int rc = i8 ? ensure_f16i8(m) : (q16 ? ensure_f16q(m) : ensure_f16s(m));
+        const bool qi8 = i8 && m->f16_q;                 // DM_OPT_F16X3_SHAPE picks the MFMA shape of both modes
+        int rc = qi8 ? ensure_f16qi(m) : i8 ? ensure_f16i8(m) : (q16 ? ensure_f16q(m) : ensure_f16s(m));
         if (rc) return rc;
         Params p;
         p.wpack = m->d_wpack16s;
         p.wpack_i8 = m->d_wpack16i;
-        for (int k = 0; k < 24; ++k) p.i8s[k] = m->i8s[k];
+        for (int k = 0; k < 24; ++k) p.i8s[k] = qi8 ? m->i8s_q[k] : m->i8s[k];
         p.hpack = m->d_wout;
         p.bout0 = m->bout[0];
         p.bout1 = m->bout[1];
@@ -735,7 +778,10 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         const int grid = std::min(2 * p.ntiles, m->grid_cap);
         if (q16) {
             p.wpack = m->d_wpack16q;
-            hipLaunchKernelGGL(lstm16q::bilstm_f16q_kernel, dim3(grid), dim3(lstm16q::THREADS), lstm16q::LDS_BYTES, m->stream, p);
+            hipLaunchKernelGGL(lstm16q::bilstm_f16q_kernel<0>, dim3(grid), dim3(lstm16q::THREADS), lstm16q::LDS_BYTES, m->stream, p);
+        } else if (qi8) {
+            p.wpack = m->d_wpack16qi;
+            hipLaunchKernelGGL(lstm16q::bilstm_f16q_kernel<1>, dim3(grid), dim3(lstm16q::THREADS), lstm16q::LDS_BYTES_I8, m->stream, p);
         } else if (i8) hipLaunchKernelGGL(bilstm_f16s_kernel<1>, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
 #ifdef DM_WITH_F16X3_ROLES
         else if (m->precision == DM_PREC_F16X3_ROLES) hipLaunchKernelGGL(lstm16r::bilstm_f16r_kernel, dim3(grid), dim3(lstm16r::THREADS_R), lstm16r::LDS_BYTES_R, m->stream, p);
@@ -1036,6 +1082,7 @@ void dm_model_destroy(dm_model* m) {
     (void)hipFree(m->d_scratch);
     (void)hipFree(m->d_wpack16s);
     (void)hipFree(m->d_wpack16q);
+    (void)hipFree(m->d_wpack16qi);
     (void)hipFree(m->d_wpack16i);
     (void)hipFree(m->d_wout);
     (void)hipFree(m->d_dbg);
@@ -1281,9 +1328,10 @@ int dm_model_calibrate_i8(dm_model* m, int64_t n_windows, double bound, double* 
     if (max_abs_dp) *max_abs_dp = double(err);
     if (double(err) <= bound && m->precision == DM_PREC_F16X3) m->precision = DM_PREC_F16I8;
     if (selected) *selected = m->precision == DM_PREC_F16I8 ? 1 : 0;      // the mode the model runs after the call
-    if (m->precision != DM_PREC_F16I8 && m->d_wpack16i) {                    // a refused model does not keep the int8 weight pack (1.7 MB)
+    if (m->precision != DM_PREC_F16I8) {                    // a refused model does not keep the int8 weight packs (1.7 MB)
         (void)hipFree(m->d_wpack16i);
-        m->d_wpack16i = nullptr;
+        (void)hipFree(m->d_wpack16qi);
+        m->d_wpack16i = m->d_wpack16qi = nullptr;
     }
     return DM_OK;
 }

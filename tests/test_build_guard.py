@@ -43,14 +43,16 @@ def test_a_stray_ablation_macro_is_a_compile_error():
         assert r.returncode != 0 and "DM_EXPERIMENT" in r.stderr, (macro, r.stderr[-300:])
 
 
-@pytest.mark.parametrize("kernel", ["f16q", "f16s", "f16i8", "f32"])
+@pytest.mark.parametrize("kernel", ["f16q", "f16qi8", "f16s", "f16i8", "f32"])
 def test_product_kernels_have_no_scratch_and_no_vgpr_spills(report, kernel):
     r = report[kernel]
     assert not r.get("missing"), "kernel symbol not found in the code object"
     res = r["resources"]
     assert res["private_segment_fixed_size"] == 0, res
     assert res["vgpr_spill_count"] == 0, res
-    if kernel != "f32":          # the fp32 kernel parks kernel arguments in VGPR lanes (v_writelane: no memory traffic)
+    if kernel == "f16qi8":       # a few scalars (fold-scale addresses) parked in VGPR lanes (v_writelane: no memory traffic)
+        assert res["sgpr_spill_count"] <= 8, res
+    elif kernel != "f32":        # the fp32 kernel parks kernel arguments in VGPR lanes
         assert res["sgpr_spill_count"] == 0, res
     assert res["vgpr_count"] <= (512 if kernel != "f32" else 256), res      # one wave per SIMD / two
 
@@ -58,7 +60,8 @@ def test_product_kernels_have_no_scratch_and_no_vgpr_spills(report, kernel):
 # MFMAs in the unrolled code of each kernel: a different count means the schedule (or the arithmetic) changed - re-run the GPU parity
 # suite and the evidence script, then update.  f16q: 1,100 (the three stages of step 0) + 2,450 (one later step);
 # f16s: 18 + 45 ... (rounds 2-4); f16i8: f16 hi*hi + layer 0's mixed k16-step, int8 cross terms; f32: 25 N-tiles x (5 + 3 + ...) k-steps
-EXPECTED_MFMA = {"f16q": {"v_mfma_f32_16x16x32_f16": 3550}, "f16s": {"v_mfma_f32_32x32x16_f16": 1872},
+EXPECTED_MFMA = {"f16q": {"v_mfma_f32_16x16x32_f16": 3550}, "f16qi8": {"v_mfma_f32_16x16x32_f16": 1450, "v_mfma_i32_16x16x64_i8": 1050},
+                 "f16s": {"v_mfma_f32_32x32x16_f16": 1872},
                  "f16i8": {"v_mfma_f32_32x32x16_f16": 845, "v_mfma_i32_32x32x32_i8": 767}, "f32": {"v_mfma_f32_16x16x4_f32": 500}}
 
 
@@ -67,7 +70,7 @@ def test_mfma_census_of_the_unrolled_body(report, kernel):
     assert report[kernel]["mfma"] == EXPECTED_MFMA[kernel]
 
 
-@pytest.mark.parametrize("kernel", ["f16q", "f16s", "f16i8", "f32"])
+@pytest.mark.parametrize("kernel", ["f16q", "f16qi8", "f16s", "f16i8", "f32"])
 def test_no_vector_instruction_reads_an_mfma_result_inside_the_hazard_window(report, kernel):
     """Every non-MFMA vector instruction that touches an MFMA's destination comes at least the required wait states later (hipcc pads
     its own code to exactly that; an inline-asm reader would show up below it, as round 4's v_min_f32 did)."""

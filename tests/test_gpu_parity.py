@@ -521,6 +521,33 @@ def test_both_mfma_shapes_behind_the_default_precision(gpu_device):
         m32.close()
 
 
+def test_both_mfma_shapes_behind_the_int8_mode(gpu_device):
+    """DM_PREC_F16I8 runs lstm16q::bilstm_f16q_kernel<1> (v_mfma_i32_16x16x64_i8 cross terms, round 5: the default shape) or, with
+    DM_OPT_F16X3_SHAPE = 32, lstm16s::bilstm_f16s_kernel<1> (v_mfma_i32_32x32x32_i8, round 3): the same reduced-precision arithmetic (int8
+    cross terms, documented bound 2e-4) on ragged sizes, three weight sets and out-of-range event lengths; the two agree with each other
+    inside that bound, and with the oracle's classes away from near ties."""
+    from deepmod_amd import _lib
+
+    def make(w, shape):
+        m = model.BiLSTMModel(w, device=gpu_device, precision="f16i8")
+        m.set_option(_lib.DM_OPT_F16X3_SHAPE, shape)
+        return m
+    for w, bound in ((synth.synthetic_weights(21, 1.0), 5e-5), (synth.synthetic_weights(26, 4.0), TOL_I8), (trained_like_weights(), 5e-5)):
+        m16, m32 = make(w, 16), make(w, 32)
+        for n in (1, 15, 16, 17, 31, 32, 33, 127, 129, 4097, 20000):
+            x = synth.synthetic_windows(n, seed=300 + n)
+            if n == 4097:
+                x[::7, :, 6] = 3.0e6                      # event lengths beyond the f16 range
+            ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
+            p16, c16 = m16.predict_windows(x)
+            p32, c32 = m32.predict_windows(x)
+            assert _check(p16, c16, ref_prob, ref_cls, TOL_I8) <= bound
+            assert _check(p32, c32, ref_prob, ref_cls, TOL_I8) <= bound
+            assert np.abs(p16 - p32).max() <= TOL_I8
+        m16.close()
+        m32.close()
+
+
 def test_selected_mode_on_read_shaped_rows(gpu_device):
     """the mode DEEPMOD_PRECISION=auto selects for the trained-like model (the load-time gate -> int8 cross terms) on
     READ-SHAPED rows - per-read feature matrices of synthetic reads with 5 % tail events (normalised means over the whole clip range,

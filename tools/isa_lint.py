@@ -22,7 +22,8 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 LIB = os.path.join(ROOT, "deepmod_amd", "csrc", "libdeepmod_hip.so")
 
 PRODUCT_KERNELS = {
-    "f16q": "_ZN7lstm16q18bilstm_f16q_kernelEN7lstm16s6ParamsE",
+    "f16q": "_ZN7lstm16q18bilstm_f16q_kernelILi0EEEvN7lstm16s6ParamsE",
+    "f16qi8": "_ZN7lstm16q18bilstm_f16q_kernelILi1EEEvN7lstm16s6ParamsE",
     "f16s": "_ZN7lstm16s18bilstm_f16s_kernelILi0EEEvNS_6ParamsE",
     "f16i8": "_ZN7lstm16s18bilstm_f16s_kernelILi1EEEvNS_6ParamsE",
     "f32": "_ZN6lstm3217bilstm_f32_kernelENS_6ParamsE",

@@ -35,7 +35,7 @@ N_BATCHES = 16                # 16 x 65,536 = 1,048,576 windows ("10^6 windows b
 FLOP_PER_WINDOW = 8.924e6     # 11 live steps x 2 dirs x 3 layers + head
 # /opt/skills/guides/MI355X_MICROARCH.md dense MFMA peaks: v_mfma_f32_16x16x4_f32 157.3 TF, 16-bit (f16/bf16) 2.5 PF
 PRECISIONS = {
-    "f16x3": {"peak": 2500.0, "kernel": "lstm16q::bilstm_f16q_kernel", "dtype": "f16x3",
+    "f16x3": {"peak": 2500.0, "kernel": "lstm16q::bilstm_f16q_kernel<0>", "dtype": "f16x3",
               "label": "split-f16 MFMA (hi+lo f16 operands, 3 products per fp32 product, fp32 accumulate), step-major: "
                        "the state of all three layers stays on the chip; 16x16x32 MFMAs (round 4), the left-over K slots' three products in one MFMA (round 5)",
               "peak_note": "v_mfma_f32_16x16x32_f16 dense 16-bit peak 2.5 PF; the kernel issues 25,600 MFMAs of 16x16x32 per 32 windows and direction "
@@ -45,14 +45,14 @@ PRECISIONS = {
                            "sustain 1.4-1.75 PF on this part at its 1,400 W limit (profiles/r02/README.md); the 32x32x16 form of rounds 2-3 "
                            "(3.09 issued per algorithmic, DM_OPT_F16X3_SHAPE = 32) is timed beside it in extras.shape_ab",
               "issued_per_algorithmic": 25600 * 16384 * 2 / 32.0 / FLOP_PER_WINDOW},
-    "f16i8": {"peak": 2500.0, "kernel": "lstm16s::bilstm_f16s_kernel<1>", "dtype": "f16+i8",
-              "label": "OPT-IN, REDUCED PRECISION: split-f16 MFMA with both cross terms of every product as one int8 MFMA (v_mfma_i32_32x32x32_i8, "
-                       "int32 accumulate, folded per tile); on 10^6 windows at weight scale 4 the worst window is 1.1e-4 from the oracle (2 above "
-                       "the path's 1e-4; the default kernel: 9e-6) - not a substitute for the default where the tolerance is binding",
-              "peak_note": "priced against the dense 16-bit peak 2.5 PF like the default: per 32 windows and direction the kernel issues 701 "
-                           "MFMA units of 32 cycles per output tile instead of 1,035 (layer 0's feature k16-step keeps three f16 products) = "
-                           "2.09 matrix units per algorithmic unit",
-              "issued_per_algorithmic": 701 * 13 * 4 * 32768 * 2 / 128.0 / FLOP_PER_WINDOW},
+    "f16i8": {"peak": 2500.0, "kernel": "lstm16q::bilstm_f16q_kernel<1>", "dtype": "f16+i8",
+              "label": "OPT-IN, REDUCED PRECISION: split-f16 MFMA with both cross terms of every product as one int8 MFMA (v_mfma_i32_16x16x64_i8 "
+                       "since round 5, int32 accumulate, folded per super-tile); on 10^6 windows at weight scale 4 the worst window is ~1e-4 from the oracle "
+                       "(the default kernel: 9e-6) - not a substitute for the default where the tolerance is binding",
+              "peak_note": "priced against the dense 16-bit peak 2.5 PF like the default: per 32 windows and direction the kernel issues 17,800 "
+                           "MFMAs of 16 cycles instead of 25,600 (the mixed k32-step keeps its three f16 products in one MFMA) = "
+                           "2.04 matrix units per algorithmic unit; the 32x32x16 form of round 3 (DM_OPT_F16X3_SHAPE = 32) is ~5 % slower",
+              "issued_per_algorithmic": 17800 * 16384 * 2 / 32.0 / FLOP_PER_WINDOW},
     "f32": {"peak": 157.3, "kernel": "lstm32::bilstm_f32_kernel", "dtype": "f32", "label": "fp32 MFMA",
             "peak_note": "v_mfma_f32_16x16x4_f32 dense fp32, 157.3 TF"},
 }
@@ -148,7 +148,7 @@ def cpu_gemm_baseline(weights, sample, cores):
     return out
 
 
-KERNEL_SOURCES = {"f16x3": ["lstm_f16q.hip.inc"], "f16i8": ["lstm_f16s.hip.inc"], "f32": ["lstm_f32.hip.inc"]}
+KERNEL_SOURCES = {"f16x3": ["lstm_f16q.hip.inc"], "f16i8": ["lstm_f16q.hip.inc"], "f32": ["lstm_f32.hip.inc"]}
 
 
 def kernel_source_sha(precision):
@@ -163,7 +163,10 @@ def kernel_source_sha(precision):
 def measured_traffic(precision):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/<round>/<precision>/pmc_summary.json of the newest round that has one: FETCH_SIZE and WRITE_SIZE in KB,
-    separate --pmc passes; gfx950 correction: FETCH_SIZE x 2 for wide coalesced reads, MI355X_MICROARCH.md HBM section).
+    separate --pmc passes; gfx950 correction: FETCH_SIZE x 2 - calibrated in round 5 on known byte counts, tools/ubench/fetch_calib.hip:
+    the counter reports exactly half the bytes both for 16-byte coalesced loads and for this kernel's own pattern, 4-byte loads of 28-byte
+    feature rows; WRITE_SIZE is exact - profiles/r05/fetch_calib.txt).  The kernel's HBM traffic is ~1.7x the algorithmic bytes because
+    the two directions of a window are separate work items that each fetch their 308-byte half in 128-byte lines; HBM runs at < 0.1 TB/s.
     `stale` is true when the kernel sources changed since that profile was taken."""
     rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r") and d[1:].isdigit())
     for rnd in reversed(rounds):
@@ -301,7 +304,7 @@ def extras(m, _lib, model, precision, x_dev0, x_host0, prob_dev, cls_dev, reps=4
             out["shape_ab"] = {"avg_launch_ms_16x16x32": ab[16], "avg_launch_ms_32x32x16": ab[32],
                                "median_ms_16x16x32": med(ab[16]), "median_ms_32x32x16": med(ab[32]),
                                "ratio_16_over_32": med(ab[16]) / med(ab[32]), "default_shape": 16,
-                               "kernels": {"16": "lstm16q::bilstm_f16q_kernel", "32": "lstm16s::bilstm_f16s_kernel<0>"},
+                               "kernels": {"16": "lstm16q::bilstm_f16q_kernel<0>", "32": "lstm16s::bilstm_f16s_kernel<0>"},
                                "timing": "same process, same batch, alternating 16 / 32 x 4; per switch %d untimed + 64 timed asynchronous launches, HIP events" % SETUP_LAUNCHES}
         finally:
             m.set_option(_lib.DM_OPT_F16X3_SHAPE, 16)

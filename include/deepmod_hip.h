@@ -60,10 +60,11 @@ extern "C" {
 #define DM_OPT_RESERVED_CUS 4 /* n in [0, CUs / 2]: the classifier's persistent grid uses CUs - n workgroups (one per CU), so that
                               small kernels of OTHER streams (the signal stage of the streaming worker) run beside a classifier
                               launch instead of waiting for it to drain.  Default 0. */
-#define DM_OPT_F16X3_SHAPE 5  /* which build of the DM_PREC_F16X3 kernel runs: 16 (default: v_mfma_f32_16x16x32_f16, lstm_f16q.hip.inc) or 32
-                              (v_mfma_f32_32x32x16_f16, lstm_f16s.hip.inc: rounds 2-3; 1-3 % slower on full launches, ~2 % faster on
-                              launches that leave most of the chip idle).  Same arithmetic, another summation order: results differ
-                              in the last bits.  The environment variable DM_F16X3_SHAPE sets the initial value at dm_model_create. */
+#define DM_OPT_F16X3_SHAPE 5  /* which build of the DM_PREC_F16X3 / DM_PREC_F16I8 kernels runs: 16 (default: v_mfma_f32_16x16x32_f16 and
+                              v_mfma_i32_16x16x64_i8, lstm_f16q.hip.inc) or 32 (v_mfma_f32_32x32x16_f16 / v_mfma_i32_32x32x32_i8,
+                              lstm_f16s.hip.inc: rounds 2-3; ~8 % / ~5 % slower on full launches since round 5).  Same arithmetic, another
+                              summation order: results differ in the last bits.  The environment variable DM_F16X3_SHAPE = 16 | 32 sets
+                              the initial value at dm_model_create (anything else is ignored with a warning). */
 #define DM_PREC_F32 0      /* fp32 MFMA (v_mfma_f32_16x16x4_f32): fp32 products, the TF graph's own arithmetic */
 #define DM_PREC_F16X3 1    /* split-f16 MFMA: every fp32 operand = hi + lo f16, 3 products per fp32 product, fp32
                               accumulation; max |dp| vs the oracle 1e-6 .. 2e-6 (tolerance of the path: 1e-4), ~3x faster.
@@ -86,8 +87,9 @@ extern "C" {
                               selectable only in a library built with -DDM_WITH_F16X3_ROLES (DM_INFO_HAS_F16X3_ROLES), otherwise
                               refused with DM_EINVAL. */
 #define DM_PREC_F16I8 3    /* OPT-IN: the step-major kernel with hi*hi in f16 and BOTH cross terms of every product as one int8 MFMA
-                              (v_mfma_i32_32x32x32_i8, int32 accumulation, folded into the fp32 pre-activations per tile): 2 issued
-                              matrix units per product instead of 3, 10-12 % less time per window.  Operands carry ~19 bits instead
+                              (v_mfma_i32_16x16x64_i8 since round 5, v_mfma_i32_32x32x32_i8 with DM_OPT_F16X3_SHAPE = 32; int32
+                              accumulation, folded into the fp32 pre-activations per tile): 2 issued matrix units per product instead
+                              of 3, 8-9 % less time per window than the default.  Operands carry ~19 bits instead
                               of 22.  REDUCED PRECISION: on 10^6 windows at weight scale 4 the worst window is 1.1e-4 from the fp32
                               graph, 2 windows exceed the path's 1e-4 tolerance and 99.99 % are below 6.5e-5 (DM_PREC_F16X3: worst
                               9e-6); at weight scale 1: 6e-6.  Documented bound 2e-4; classes equal wherever p1 is further than that

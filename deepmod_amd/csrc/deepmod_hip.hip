@@ -1,26 +1,7 @@
-// deepmod_hip.hip — libdeepmod_hip.so: C ABI (include/deepmod_hip.h) + host runtime for gfx950.
-// Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see __graft_entry__.build()).
-#include <hip/hip_runtime.h>
-
-// ---- experiment switches (round 5: one umbrella) ------------------------------------------------------------------------------------------
-// Every macro below turns a product kernel into a TIMING-ONLY or otherwise experimental build (tools/ablate.py).  None of them may reach
-// the product by accident: without -DDM_EXPERIMENT any of them is a compile error, and dm_build_flags() reports what a library was built with
-// (tests/test_build_guard.py checks the shipped library says "experiment=0").
-#if defined(DM16Q_ABL_NOCELL) || defined(DM16Q_ABL_NODMA) || defined(DM16Q_ABL_MIX1) || defined(DM16Q_ABL_I8T) || defined(DM16Q_AINIT) || defined(DM16Q_DEBUG_NOP) ||           \
-    defined(DM16Q_NOCHUNK) || defined(DM16Q_NOPN) || defined(DM16Q_PRE) || defined(DM16Q_SNAKE) || defined(DM16Q_TRANS_COST) ||                     \
-    defined(DM16S_ABL_2PROD) || defined(DM16S_ABL_B64) || defined(DM16S_ABL_LO_ONLY) || defined(DM16S_ABL_MFMA16) ||                              \
-    defined(DM16S_ABL_MFMA16_PAD) || defined(DM16S_ABL_NOBAR) || defined(DM16S_ABL_NOCELL) || defined(DM16S_ABL_NODMA) ||                          \
-    defined(DM16S_ABL_NOLDSA) || defined(DM16S_ADIST) || defined(DM16S_ALO_TRUNC) || defined(DM16S_PRE) || defined(DM_ABL_NOBAR) ||                \
-    defined(DM_ABL_NODMA) || defined(DM_ABL_NOEPI) || defined(DM_ABL_NOSEQ) || defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2) ||   \
-    defined(DM_WLO_TRUNC_ENV) || defined(DM_WLO_TRUNC_DEFAULT) || defined(DM_WITH_F16X3_ROLES) || defined(DM16R_DMA_M) ||                         \
-    defined(DM_F16X3_SHAPE_DEFAULT) || defined(DM_WAVES) || defined(DM_MT)
-#define DM_ANY_EXPERIMENT_SWITCH 1
-#ifndef DM_EXPERIMENT
-#error "an ablation / experiment macro is defined without -DDM_EXPERIMENT: timing-only kernels must not be built into the product by a stray -D"
-#endif
-#else
-#define DM_ANY_EXPERIMENT_SWITCH 0
-#endif
+// deepmod_hip.hip — libdeepmod_hip.so: C ABI (include/deepmod_hip.h) + host runtime for gfx950 + the small kernels (head, summary,
+// cluster, calibration, signal).  The three classifier kernel families are separate translation units (kern_*.hip, interface: kernels.h);
+// __graft_entry__.build() compiles the five in parallel (hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c) and links them.
+#include "kernels.h"
 
 #include <dlfcn.h>
 
@@ -37,14 +18,9 @@
 
 #include "../../include/deepmod_hip.h"
 #include "head.hip.inc"
-#include "lstm_f32.hip.inc"
-#include "lstm_f16s.hip.inc"
-#include "lstm_f16q.hip.inc"
-#ifdef DM_WITH_F16X3_ROLES   // the matrix / cell wave-pair form of the default kernel (round 4): an experiment build, not part of the product
-#include "../../tools/experiments/f16r/lstm_f16r.hip.inc"
-#endif
 
-
+using dmk::Packed16;
+using dmk::Packed32;
 
 namespace {
 
@@ -76,379 +52,6 @@ bool is_device_ptr(const void* p) {
         return false;
     }
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
-}
-
-// ---------------------------------------------------------------------------------------------
-// weight packing (host): canonical flat blob -> MFMA consumption order
-// ---------------------------------------------------------------------------------------------
-// column of the TF kernel ([.., 400] = i|j|f|o blocks of 100) held by N-tile t, tile column c
-inline int gate_col(int t, int c) {
-    if (t < 24) return (t & 3) * 100 + 16 * (t >> 2) + c;
-    return (c >> 2) * 100 + 96 + (c & 3);
-}
-// exponent scale folded into kernel and bias columns (both kernels): the cell update takes 2^x of the accumulators as
-// they are - i, f, o columns x -log2(e) (sigmoid = 1 / (1 + 2^a)), j column x 2 log2(e) (tanh = (2^a - 1) / (2^a + 1))
-inline float gate_scale(int gc) { return (gc >= 100 && gc < 200) ? 2.8853900817779268f : -1.4426950408889634f; }
-
-struct Packed {
-    std::vector<float> w, b, h;
-    float bout[2];
-};
-
-Packed pack_weights(const float* flat) {
-    using namespace lstm32;
-    Packed P;
-    P.w.assign(size_t(2) * KS_DIR * KSTEP_F, 0.0f);
-    P.b.assign(size_t(6) * 400, 0.0f);
-    P.h.assign(size_t(2) * 25 * 64, 0.0f);
-    const float* p = flat;
-    for (int d = 0; d < 2; ++d) {
-        int ks_base = 0;
-        for (int l = 0; l < 3; ++l) {
-            const int kin = l == 0 ? NFEAT : HID;
-            const int ksin = l == 0 ? 2 : 25;
-            const float* kern = p;
-            p += size_t(kin + HID) * 400;
-            const float* bias = p;
-            p += 400;
-            for (int ks = 0; ks < ksin + 25; ++ks) {
-                float* dst = P.w.data() + size_t(d * KS_DIR + ks_base + ks) * KSTEP_F;
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int sub = lane >> 4, c = lane & 15;
-                    int krow;  // row of the TF kernel feeding this (k-step, sub-k); -1 = zero padding
-                    if (ks < ksin) {
-                        const int k = 4 * ks + sub;
-                        krow = k < kin ? k : -1;
-                    } else {
-                        krow = kin + 4 * (ks - ksin) + sub;
-                    }
-                    for (int t = 0; t < NT; ++t) {
-                        const float v = krow < 0 ? 0.0f : kern[size_t(krow) * 400 + gate_col(t, c)] * gate_scale(gate_col(t, c));
-                        if (t < 24) dst[((t >> 2) * 64 + lane) * 4 + (t & 3)] = v;   // [tile quad][lane][4]
-                        else dst[6 * 256 + lane] = v;                                // tile 24: [lane]
-                    }
-                }
-            }
-            float* bd = P.b.data() + size_t(d * 3 + l) * 400;
-            for (int t = 0; t < NT; ++t)
-                for (int c = 0; c < 16; ++c) {
-                    const int gc = gate_col(t, c);
-                    bd[t * 16 + c] = (bias[gc] + ((gc >= 200 && gc < 300) ? 1.0f : 0.0f)) * gate_scale(gc);  // forget_bias=1.0
-                }
-            ks_base += ksin + 25;
-        }
-    }
-    const float* wout = p;  // [200][2]
-    const float* bo = p + 400;
-    for (int d = 0; d < 2; ++d)
-        for (int kh = 0; kh < 25; ++kh)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int c = lane & 15, sub = lane >> 4;
-                P.h[(size_t(d) * 25 + kh) * 64 + lane] = c < 2 ? wout[(d * HID + 4 * kh + sub) * 2 + c] : 0.0f;
-            }
-    P.bout[0] = bo[0];
-    P.bout[1] = bo[1];
-    return P;
-}
-
-// split-f16 packing: [dir][stream position][tile][hi|lo][lane][8 x f16], k-steps in the kernel's stream order
-struct Packed16 {
-    std::vector<unsigned char> w;
-    float max_abs = 0.0f;   // largest |packed value| (after the exponent-scale fold): must stay <= 65504 to be an f16
-    bool finite = true;
-    int len_shift = 0;      // the weight row of feature 6 (event length) is stored a second time x 2^len_shift (slot 7)
-};
-
-// len_shift: the largest k <= 10 for which (length row x exponent scale x 2^k) is still an f16: an event length beyond
-// 65504 samples is then fed as v * 2^-k through slot 7 (exact power-of-two rescale; covers |v| <= 65504 * 2^k)
-int choose_len_shift(const float* flat) {
-    float m = 0.0f;
-    const float* p = flat;
-    for (int d = 0; d < 2; ++d) {
-        const float* row = p + size_t(lstmhead::NFEAT - 1) * 400;          // layer-0 kernel row of feature 6
-        for (int gc = 0; gc < 400; ++gc) m = std::max(m, std::fabs(row[gc] * gate_scale(gc)));
-        p += size_t(lstmhead::NFEAT + lstmhead::HID) * 400 + 400 + 2 * (size_t(2 * lstmhead::HID) * 400 + 400);
-    }
-    int k = 10;
-    while (k > 0 && !(m * std::ldexp(1.0f, k) <= 32768.0f)) --k;
-    return k;
-}
-
-
-// 16x16x32 packing (lstm_f16q.hip.inc): [dir][layer][super-tile S][records in the kernel's processing order].
-// A-operand lane l of a 16-row tile: row m = l % 16 -> unit 8S + 4 rh + m / 4, gate m % 4; k = (g = l / 16, j = 0..7) -> K slot of the B operand.
-//   own t = 0..2 / input t = 0..2 (layers 1, 2), 4 KB each, [row half][hi|lo][lane][8 x f16]: slot j = own / input unit 8 (4t + j/2) + 4 (j%2) + g
-//   mixed, 2 KB, [row half][lane][8 x f16] - the three products of the left-over slots side by side (round 5):
-//       j = 0, 1, 2: (hi, lo, hi) of the weight of own unit 96 + g      against the B slots (h_hi, h_hi, h_lo)
-//       j = 3, 4, 5: (hi, lo, hi) of the weight of input unit 96 + g (layer 0: of feature g) against (x_hi, x_hi, x_lo)
-//       j = 6, 7   : g = 0: (hi, lo) of the bias row against (1, 1); else zero
-//   layer 0 only, a second mixed record: j = 0, 1, 2, 3: (hi, lo, hi, lo) of the weight of feature 4 + g (g = 3: the event length x 2^len_shift)
-//       against (x_hi, x_hi, x_lo, x_lo) - all FOUR products of the signal features (event lengths reach 10^4); j >= 4: zero
-// int8 = true (DM_PREC_F16I8 on this shape, round 5): the second KB of a row half of an ORDINARY record holds, instead of the lo f16 halves, the int8
-// cross-term weights of the same 32 K slots: bytes (2j, 2j + 1) of lane l = (w_hi8, w_lo8) of the unit of slot j - they meet the B bytes (lo8, hi8) of that
-// unit in one v_mfma_i32_16x16x64_i8.  Scales per (direction, layer, gate kind) exactly as in pack_weights_tile below: sw = max(|w_hi|, 2^12 |w_lo|) over the
-// rows that ride the int8 product (own / input units 0..95), i8s = sw 2^-12 / 127^2.  The mixed records keep their f16 form.
-Packed16 pack_weights_q(const float* flat, const bool int8 = false, float* i8s = nullptr) {
-    using namespace lstm16q;
-    Packed16 P;
-    P.w.assign(WEIGHT_BYTES, 0);
-    P.len_shift = choose_len_shift(flat);
-    const float len_mul = std::ldexp(1.0f, P.len_shift);
-    const float* p = flat;
-    auto split = [&](float v, _Float16& hi, _Float16& lo) {
-        if (!std::isfinite(v)) P.finite = false;
-        else P.max_abs = std::max(P.max_abs, std::fabs(v));
-        hi = (_Float16)v;
-        lo = (_Float16)(v - (float)hi);
-    };
-    for (int d = 0; d < 2; ++d) {
-        size_t off = size_t(d) * WEIGHT_BYTES_DIR;
-        for (int l = 0; l < 3; ++l) {
-            const int kin = l == 0 ? NFEAT : HID;
-            const float* kern = p;
-            const float* bias = p + size_t(kin + HID) * 400;
-            p += size_t(kin + HID) * 400 + 400;
-            // weight of TF kernel row krow (-2: the bias row, -1: nothing) for gate column gc, exponent scale folded
-            auto wval = [&](int krow, int gc, float mul) {
-                if (krow >= 0) return kern[size_t(krow) * 400 + gc] * gate_scale(gc) * mul;
-                if (krow == -2) return (bias[gc] + (gc >= 200 && gc < 300 ? 1.0f : 0.0f)) * gate_scale(gc);
-                return 0.0f;
-            };
-            float sw[4] = {1.f, 1.f, 1.f, 1.f};
-            if (int8) {
-                for (int gk = 0; gk < 4; ++gk) {
-                    float m = 0.0f;
-                    for (int u = 0; u < HID; ++u)
-                        for (int krow = (l == 0 ? kin : 0); krow < kin + 96; ++krow) {
-                            if (l > 0 && krow >= 96 && krow < kin) continue;          // input units 96..99 ride the mixed record
-                            const float v = wval(krow, gk * 100 + u, 1.0f);
-                            const _Float16 hi = (_Float16)v;
-                            const _Float16 lo = (_Float16)(v - (float)hi);
-                            m = std::max(m, std::max(std::fabs((float)hi), 4096.0f * std::fabs((float)lo)));
-                        }
-                    sw[gk] = m > 0.0f ? m : 1.0f;
-                    if (i8s) i8s[(d * 3 + l) * 4 + gk] = sw[gk] / (4096.0f * 127.0f * 127.0f);
-                }
-            }
-            for (int S = 0; S < NTILE; ++S) {
-                // ordinary records: own 0..2, then (layers 1, 2) input 0..2
-                for (int rec = 0; rec < (l == 0 ? 3 : 6); ++rec) {
-                    _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + off);
-                    signed char* dst8 = reinterpret_cast<signed char*>(P.w.data() + off);
-                    off += REC_BYTES;
-                    const bool is_own = rec < 3;
-                    const int t = is_own ? rec : rec - 3;
-                    for (int rh = 0; rh < 2; ++rh)
-                        for (int lane = 0; lane < 64; ++lane) {
-                            const int m = lane & 15, g = lane >> 4;
-                            const int unit = 8 * S + 4 * rh + m / 4, gate = m % 4;
-                            for (int j = 0; j < 8; ++j) {
-                                _Float16 hi = (_Float16)0.0f, lo = (_Float16)0.0f;
-                                if (unit < HID) split(wval((is_own ? kin : 0) + 8 * (4 * t + j / 2) + 4 * (j % 2) + g, gate * 100 + unit, 1.0f), hi, lo);
-                                dst[((size_t(rh) * 2 + 0) * 64 + lane) * 8 + j] = hi;
-                                if (!int8) dst[((size_t(rh) * 2 + 1) * 64 + lane) * 8 + j] = lo;
-                                else {
-                                    const float s8 = 127.0f / sw[gate];
-                                    const float qh = std::nearbyint((float)hi * s8), ql = std::nearbyint((float)lo * s8 * 4096.0f);
-                                    signed char* d8 = dst8 + (size_t(rh) * 2 + 1) * 1024 + size_t(lane) * 16 + 2 * j;
-                                    d8[0] = (signed char)std::max(-127.0f, std::min(127.0f, qh));
-                                    d8[1] = (signed char)std::max(-127.0f, std::min(127.0f, ql));
-                                }
-                            }
-                        }
-                }
-                // mixed record(s)
-                for (int mrec = 0; mrec < (l == 0 ? 2 : 1); ++mrec) {
-                    _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + off);
-                    off += MIX_BYTES;
-                    for (int rh = 0; rh < 2; ++rh)
-                        for (int lane = 0; lane < 64; ++lane) {
-                            const int m = lane & 15, g = lane >> 4;
-                            const int unit = 8 * S + 4 * rh + m / 4, gate = m % 4;
-                            _Float16 slot[8];
-                            for (int j = 0; j < 8; ++j) slot[j] = (_Float16)0.0f;
-                            if (unit < HID) {
-                                const int gc = gate * 100 + unit;
-                                _Float16 hi, lo;
-                                if (mrec == 0) {
-                                    split(wval(kin + 96 + g, gc, 1.0f), hi, lo);
-                                    slot[0] = hi; slot[1] = lo; slot[2] = hi;
-                                    split(wval(l == 0 ? g : 96 + g, gc, 1.0f), hi, lo);
-                                    slot[3] = hi; slot[4] = lo; slot[5] = hi;
-                                    if (g == 0) {
-                                        split(wval(-2, gc, 1.0f), hi, lo);
-                                        slot[6] = hi; slot[7] = lo;
-                                    }
-                                } else {
-                                    split(g < 3 ? wval(4 + g, gc, 1.0f) : wval(NFEAT - 1, gc, len_mul), hi, lo);
-                                    slot[0] = hi; slot[1] = lo; slot[2] = hi; slot[3] = lo;      // j = 3: x_lo w_lo, the fourth product (free slot)
-                                }
-                            }
-                            for (int j = 0; j < 8; ++j) dst[(size_t(rh) * 64 + lane) * 8 + j] = slot[j];
-                        }
-                }
-            }
-        }
-    }
-    return P;
-}
-
-// tile-major split-f16 packing (lstm_f16s.hip.inc): [dir][layer][tile][k16-step][hi|lo][lane][8 x f16].
-// A-operand lane l of record (tile T, k16-step t): gate row m = l % 32 -> unit 8T + m / 4, gate m % 4;
-// k = (half = l / 32, j = 0..7) -> K slot of the B operand the kernel builds in registers:
-//   t < 6 : own unit 8 (2t + j/4) + 2 (j%4) + half
-//   t == 6: j < 4: own unit 96 + 2j + half (slot 100 = the constant 1.0 -> bias row; 101..103 zero);
-//           j >= 4: layer 0: feature 2 (j-4) + half (7 = event length x 2^-len_shift); layers 1, 2: input unit 96 + 2 (j-4) + half
-//   t > 6 : input unit 8 (2 (t-7) + j/4) + 2 (j%4) + half
-// int8 = true (DM_PREC_F16I8): the second KB of a record holds, instead of the lo f16 halves, the int8 cross-term weights of the
-// same 16 K slots: bytes (2j, 2j + 1) of lane l = (w_hi8, w_lo8) of the unit of slot j - they meet the B bytes (lo8, hi8) of that
-// unit in one v_mfma_i32_32x32x32_i8.  Scales, per (direction, layer, gate kind g): sw = max(|w_hi|, 2^12 |w_lo|) over the gate's
-// rows; w_hi8 = rint(127 w_hi / sw), w_lo8 = rint(127 * 2^12 w_lo / sw); with lo8 = rint(127 * 2^12 h_lo) and hi8 = rint(127 h) one
-// count of the int32 accumulator is i8s = sw 2^-12 / 127^2 pre-activation units for both slots.  Layer 0's mixed k16-step
-// (t = 6: own units 96..99, bias slot, RAW features) keeps its f16 lo record: the kernel runs it with three f16 products.
-// (An int32 accumulator cannot overflow: 2 * 208 slots * 127 * 127 < 2^23.)
-#ifndef DM_F16X3_SHAPE_DEFAULT
-#define DM_F16X3_SHAPE_DEFAULT 16
-#endif
-#ifndef DM_WLO_TRUNC_DEFAULT
-#define DM_WLO_TRUNC_DEFAULT 0
-#endif
-#include <cstdlib>
-// lo half of a weight with its low m mantissa bits rounded away (round to nearest even on the bit pattern; m = 0: unchanged)
-static inline _Float16 round_lo_bits(_Float16 lo, int m) {
-    if (m <= 0) return lo;
-    unsigned short b;
-    std::memcpy(&b, &lo, 2);
-    const unsigned short sign = b & 0x8000u;
-    unsigned mag = b & 0x7FFFu;
-    const unsigned half = 1u << (m - 1), lsb = (mag >> m) & 1u;
-    mag = (mag + half - 1u + lsb) & ~((1u << m) - 1u);      // a carry into the exponent is the right value (next binade)
-    if (mag >= 0x7C00u) mag = 0x7BFFu & ~((1u << m) - 1u);
-    b = (unsigned short)(sign | mag);
-    std::memcpy(&lo, &b, 2);
-    return lo;
-}
-// The operand-toggle dial of round 4 (profiles/r04/lo_trunc_dial.txt: closed, not adopted - already m = 3 leaves the 3e-5 bar for a
-// change of arithmetic and returns < 1.5 %).  The product packs full lo halves; only an experiment build (-DDM_WLO_TRUNC_ENV,
-// tools/lo_trunc_dial.py) reads the knob from the environment.
-static int wlo_trunc_bits() {
-#ifdef DM_WLO_TRUNC_ENV
-    const char* e = std::getenv("DM_WLO_TRUNC");
-    if (e && *e) {
-        const int m = std::atoi(e);
-        return m < 0 ? 0 : (m > 9 ? 9 : m);
-    }
-#endif
-    return DM_WLO_TRUNC_DEFAULT;
-}
-
-Packed16 pack_weights_tile(const float* flat, const bool int8 = false, float* i8s = nullptr) {
-    using namespace lstm16s;
-    const int wlo_m = int8 ? 0 : wlo_trunc_bits();
-    Packed16 P;
-    P.w.assign(WEIGHT_BYTES, 0);
-    P.len_shift = choose_len_shift(flat);
-    const float len_mul = std::ldexp(1.0f, P.len_shift);
-    const float* p = flat;
-    for (int d = 0; d < 2; ++d) {
-        size_t off = size_t(d) * WEIGHT_BYTES_DIR;
-        for (int l = 0; l < 3; ++l) {
-            const int kin = l == 0 ? NFEAT : HID;
-            const int nks = l == 0 ? KS_L0 : KS_L12;
-            const float* kern = p;
-            const float* bias = p + size_t(kin + HID) * 400;
-            p += size_t(kin + HID) * 400 + 400;
-            float sw[4] = {0.f, 0.f, 0.f, 0.f};
-            constexpr float MAGIC = 0.0f;     // (a bias-row offset for accumulators that would not start from 0: none)
-            // value of (TF kernel row krow | bias row = kin + HID, gate column gc) as the int8 pack stores it
-            auto packed_value = [&](int krow, int gc, const float* swp) {
-                if (krow < kin + HID) return kern[size_t(krow) * 400 + gc] * gate_scale(gc);
-                return (bias[gc] + (gc / 100 == 2 ? 1.0f : 0.0f)) * gate_scale(gc) - (int8 ? swp[gc / 100] / (4096.0f * 127.0f * 127.0f) * MAGIC : 0.0f);
-            };
-            if (int8) {      // every value that rides the int8 product: the recurrent rows, layers 1, 2 also the input rows, the bias row
-                for (int gk = 0; gk < 4; ++gk) {
-                    float m = 0.0f;
-                    for (int u = 0; u < HID; ++u)
-                        for (int krow = (l == 0 ? NFEAT : 0); krow <= kin + HID; ++krow) {
-                            const float v = packed_value(krow, gk * 100 + u, sw);     // (bias offset of sw = 0: the loop below settles it)
-                            const _Float16 hi = (_Float16)v;
-                            const _Float16 lo = (_Float16)(v - (float)hi);
-                            m = std::max(m, std::max(std::fabs((float)hi), 4096.0f * std::fabs((float)lo)));
-                        }
-                    sw[gk] = m > 0.0f ? m : 1.0f;
-                    for (int tries = 0; tries < 64; ++tries) {        // representable with this sw, and no row can leave (-2^22, 2^22)?
-                        bool ok = true;
-                        for (int u = 0; u < HID && ok; ++u) {
-                            double worst = 0.0;
-                            for (int krow = (l == 0 ? NFEAT : 0); krow <= kin + HID; ++krow) {
-                                const float v = packed_value(krow, gk * 100 + u, sw);
-                                const _Float16 hi = (_Float16)v;
-                                const _Float16 lo = (_Float16)(v - (float)hi);
-                                const float qh = std::fabs((float)hi) * 127.0f / sw[gk], ql = std::fabs((float)lo) * 4096.0f * 127.0f / sw[gk];
-                                if (qh > 127.0f || ql > 127.0f) ok = false;
-                                worst += 127.0 * (std::nearbyint(std::min(qh, 127.0f)) + std::nearbyint(std::min(ql, 127.0f)));
-                            }
-                            (void)worst;
-                        }
-                        if (ok) break;
-                        sw[gk] *= 1.125f;
-                    }
-                    if (i8s) i8s[(d * 3 + l) * 4 + gk] = sw[gk] / (4096.0f * 127.0f * 127.0f);
-                }
-            }
-            for (int T = 0; T < NTILE; ++T)
-                for (int t = 0; t < nks; ++t) {
-                    _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + off);
-                    signed char* dst8 = reinterpret_cast<signed char*>(P.w.data() + off + REC_BYTES / 2);
-                    const bool rec8 = int8 && !(l == 0 && t == 6);
-                    off += REC_BYTES;
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int m = lane & 31, half = lane >> 5;
-                        const int unit = 8 * T + m / 4, gate = m % 4;
-                        for (int j = 0; j < 8; ++j) {
-                            float v = 0.0f;
-                            if (unit < HID) {
-                                const int gc = gate * 100 + unit;
-                                int krow = -1;          // row of the TF kernel; -2 = bias row; -1 = zero
-                                float mul = 1.0f;
-                                if (t < 6 || (t == 6 && j < 4)) {                       // own hidden state
-                                    const int u = t < 6 ? 8 * (2 * t + j / 4) + 2 * (j % 4) + half : 96 + 2 * j + half;
-                                    if (u < HID) krow = kin + u;
-                                    else if (u == HID) krow = -2;
-                                } else if (t == 6) {
-                                    const int f = 2 * (j - 4) + half;
-                                    if (l == 0) {
-                                        if (f < NFEAT) krow = f;
-                                        else {
-                                            krow = NFEAT - 1;
-                                            mul = len_mul;
-                                        }
-                                    } else if (96 + f < HID) krow = 96 + f;
-                                } else {
-                                    const int u = 8 * (2 * (t - 7) + j / 4) + 2 * (j % 4) + half;
-                                    if (u < HID) krow = u;
-                                }
-                                if (krow >= 0) v = kern[size_t(krow) * 400 + gc] * gate_scale(gc) * mul;
-                                else if (krow == -2) v = packed_value(kin + HID, gc, sw);        // bias + forget_bias (int8 pack: - i8s * MAGIC)
-                            }
-                            if (!std::isfinite(v)) P.finite = false;
-                            else P.max_abs = std::max(P.max_abs, std::fabs(v));
-                            const _Float16 hi = (_Float16)v;
-                            const _Float16 lo = (_Float16)(v - (float)hi);
-                            dst[(0 * 64 + lane) * 8 + j] = hi;
-                            if (!rec8) dst[(1 * 64 + lane) * 8 + j] = round_lo_bits(lo, wlo_m);
-                            else {
-                                const float s8 = 127.0f / sw[gate];
-                                const float qh = std::nearbyint((float)hi * s8), ql = std::nearbyint((float)lo * s8 * 4096.0f);
-                                dst8[lane * 16 + 2 * j] = (signed char)std::max(-127.0f, std::min(127.0f, qh));
-                                dst8[lane * 16 + 2 * j + 1] = (signed char)std::max(-127.0f, std::min(127.0f, ql));
-                            }
-                        }
-                    }
-                }
-        }
-    }
-    return P;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -676,56 +279,39 @@ int ensure_f16_common(dm_model* m) {
     return DM_OK;
 }
 
+// one weight pack per (shape, mode), built on first use
+int ensure_pack(dm_model* m, unsigned char*& d_pack, const Packed16& P, hipError_t prepared) {
+    if (prepared != hipSuccess) return fail(DM_EDEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(prepared));
+    HIP_TRY(hipMalloc(&d_pack, P.w.size()));
+    HIP_TRY(hipMemcpy(d_pack, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
+    return DM_OK;
+}
 int ensure_f16s(dm_model* m) {
     if (m->d_wpack16s) return DM_OK;
     int rc = ensure_f16_common(m);
     if (rc) return rc;
-    Packed16 P = pack_weights_tile(m->host_weights.data());
-    HIP_TRY(hipMalloc(&m->d_wpack16s, P.w.size()));
-    HIP_TRY(hipMemcpy(m->d_wpack16s, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16s::bilstm_f16s_kernel<0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16s::LDS_BYTES)));
-#ifdef DM_WITH_F16X3_ROLES
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16r::bilstm_f16r_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16r::LDS_BYTES_R)));
-#endif
+    rc = ensure_pack(m, m->d_wpack16s, dmk::pack_weights_f16s(m->host_weights.data()), dmk::f16s_prepare(0));
+    if (rc) return rc;
+    if (dmk::f16s_has_roles() && dmk::f16s_prepare(2) != hipSuccess) return fail(DM_EDEVICE, "the roles kernel cannot be prepared");
     return DM_OK;
 }
-
 int ensure_f16q(dm_model* m) {
     if (m->d_wpack16q) return DM_OK;
     int rc = ensure_f16_common(m);
     if (rc) return rc;
-    Packed16 P = pack_weights_q(m->host_weights.data());
-    HIP_TRY(hipMalloc(&m->d_wpack16q, P.w.size()));
-    HIP_TRY(hipMemcpy(m->d_wpack16q, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16q::bilstm_f16q_kernel<0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16q::LDS_BYTES)));
-    return DM_OK;
+    return ensure_pack(m, m->d_wpack16q, dmk::pack_weights_f16q(m->host_weights.data()), dmk::f16q_prepare(0));
 }
-
 int ensure_f16qi(dm_model* m) {
     if (m->d_wpack16qi) return DM_OK;
     int rc = ensure_f16_common(m);
     if (rc) return rc;
-    Packed16 P = pack_weights_q(m->host_weights.data(), true, m->i8s_q);
-    HIP_TRY(hipMalloc(&m->d_wpack16qi, P.w.size()));
-    HIP_TRY(hipMemcpy(m->d_wpack16qi, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16q::bilstm_f16q_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16q::LDS_BYTES_I8)));
-    return DM_OK;
+    return ensure_pack(m, m->d_wpack16qi, dmk::pack_weights_f16q(m->host_weights.data(), true, m->i8s_q), dmk::f16q_prepare(1));
 }
-
 int ensure_f16i8(dm_model* m) {
     if (m->d_wpack16i) return DM_OK;
     int rc = ensure_f16_common(m);
     if (rc) return rc;
-    Packed16 P = pack_weights_tile(m->host_weights.data(), true, m->i8s);
-    HIP_TRY(hipMalloc(&m->d_wpack16i, P.w.size()));
-    HIP_TRY(hipMemcpy(m->d_wpack16i, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16s::bilstm_f16s_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16s::LDS_BYTES)));
-    return DM_OK;
+    return ensure_pack(m, m->d_wpack16i, dmk::pack_weights_f16s(m->host_weights.data(), true, m->i8s), dmk::f16s_prepare(1));
 }
 
 
@@ -750,78 +336,55 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         ++m->events_used;
         HIP_TRY(hipEventRecord(e0, m->stream));
     }
+    const int ntiles = int((n + dmk::TILE_M - 1) / dmk::TILE_M);
+    {
+        int rcp = ensure_plogit(m, ntiles);
+        if (rcp) return rcp;
+    }
+    const long long npad = (long long)ntiles * dmk::TILE_M;
+    const int grid = std::min(2 * ntiles, m->grid_cap);          // work item = (tile, direction)
     if (m->precision == DM_PREC_F16X3 || m->precision == DM_PREC_F16I8 || m->precision == DM_PREC_F16X3_ROLES) {
-        using namespace lstm16s;
         const bool i8 = m->precision == DM_PREC_F16I8;
         const bool q16 = m->precision == DM_PREC_F16X3 && m->f16_q;
         const bool qi8 = i8 && m->f16_q;                 // DM_OPT_F16X3_SHAPE picks the MFMA shape of both modes
         int rc = qi8 ? ensure_f16qi(m) : i8 ? ensure_f16i8(m) : (q16 ? ensure_f16q(m) : ensure_f16s(m));
         if (rc) return rc;
-        Params p;
-        p.wpack = m->d_wpack16s;
-        p.wpack_i8 = m->d_wpack16i;
-        for (int k = 0; k < 24; ++k) p.i8s[k] = qi8 ? m->i8s_q[k] : m->i8s[k];
-        p.hpack = m->d_wout;
-        p.bout0 = m->bout[0];
-        p.bout1 = m->bout[1];
-        p.x = d_x;
-        p.xstride = xstride;
-        p.widx = d_widx;
-        p.n = n;
-        p.ntiles = int((n + TILE_M - 1) / TILE_M);
-        int rcp = ensure_plogit(m, p.ntiles);
-        if (rcp) return rcp;
-        p.plogit = m->d_plogit;
-        p.len_scale = std::ldexp(1.0f, -m->len_shift);
-        p.len_mul = std::ldexp(1.0f, m->len_shift);
-        p.range_flag = m->d_range_flag + m->range_cur;
-        const int grid = std::min(2 * p.ntiles, m->grid_cap);
-        if (q16) {
-            p.wpack = m->d_wpack16q;
-            hipLaunchKernelGGL(lstm16q::bilstm_f16q_kernel<0>, dim3(grid), dim3(lstm16q::THREADS), lstm16q::LDS_BYTES, m->stream, p);
-        } else if (qi8) {
-            p.wpack = m->d_wpack16qi;
-            hipLaunchKernelGGL(lstm16q::bilstm_f16q_kernel<1>, dim3(grid), dim3(lstm16q::THREADS), lstm16q::LDS_BYTES_I8, m->stream, p);
-        } else if (i8) hipLaunchKernelGGL(bilstm_f16s_kernel<1>, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
-#ifdef DM_WITH_F16X3_ROLES
-        else if (m->precision == DM_PREC_F16X3_ROLES) hipLaunchKernelGGL(lstm16r::bilstm_f16r_kernel, dim3(grid), dim3(lstm16r::THREADS_R), lstm16r::LDS_BYTES_R, m->stream, p);
-#endif
-        else hipLaunchKernelGGL(bilstm_f16s_kernel<0>, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
-        const long long npad = (long long)p.ntiles * TILE_M;
-        hipLaunchKernelGGL(lstmhead::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
-                           npad, m->bout[0], m->bout[1], d_prob, d_cls);
-    } else
-    {
-        using namespace lstm32;
-        Params p;
-        p.wpack = m->d_wpack;
-        p.bpack = m->d_bpack;
-        p.hpack = m->d_hpack;
-        p.bout0 = m->bout[0];
-        p.bout1 = m->bout[1];
-        p.x = d_x;
-        p.xstride = xstride;
-        p.widx = d_widx;
-        p.n = n;
-        p.prob = d_prob;
-        p.cls = d_cls;
-        p.scratch = m->d_scratch;
-        p.ntiles = int((n + TILE_M - 1) / TILE_M);
-        p.dbg = m->d_dbg;
-        p.dir_split = 1;      // work item = (tile, direction), see above
-        {
-            int rcp = ensure_plogit(m, p.ntiles);
-            if (rcp) return rcp;
-        }
-        p.plogit = m->d_plogit;
-        const int grid = std::min(p.dir_split ? 2 * p.ntiles : p.ntiles, m->grid_cap);
-        hipLaunchKernelGGL(bilstm_f32_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, m->stream, p);
-        if (p.dir_split) {
-            const long long npad = (long long)p.ntiles * TILE_M;
-            hipLaunchKernelGGL(lstmhead::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit,
-                               (long long)n, npad, m->bout[0], m->bout[1], d_prob, d_cls);
-        }
+        dmk::F16Args a;
+        a.wpack = qi8 ? m->d_wpack16qi : i8 ? m->d_wpack16i : q16 ? m->d_wpack16q : m->d_wpack16s;
+        a.hpack = m->d_wout;
+        a.x = d_x;
+        a.xstride = xstride;
+        a.widx = d_widx;
+        a.n = n;
+        a.ntiles = ntiles;
+        a.plogit = m->d_plogit;
+        a.len_shift = m->len_shift;
+        a.range_flag = m->d_range_flag + m->range_cur;
+        a.i8s = qi8 ? m->i8s_q : i8 ? m->i8s : nullptr;
+        if (q16 || qi8) dmk::f16q_launch(qi8 ? 1 : 0, a, grid, m->stream);
+        else dmk::f16s_launch(i8 ? 1 : (m->precision == DM_PREC_F16X3_ROLES ? 2 : 0), a, grid, m->stream);
+    } else {
+        dmk::F32Args a;
+        a.wpack = m->d_wpack;
+        a.bpack = m->d_bpack;
+        a.hpack = m->d_hpack;
+        a.bout0 = m->bout[0];
+        a.bout1 = m->bout[1];
+        a.x = d_x;
+        a.xstride = xstride;
+        a.widx = d_widx;
+        a.n = n;
+        a.prob = d_prob;
+        a.cls = d_cls;
+        a.scratch = m->d_scratch;
+        a.ntiles = ntiles;
+        a.dbg = m->d_dbg;
+        a.dir_split = 1;      // work item = (tile, direction), see above
+        a.plogit = m->d_plogit;
+        dmk::f32_launch(a, grid, m->stream);
     }
+    hipLaunchKernelGGL(lstmhead::head_finish_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, m->stream, m->d_plogit, (long long)n,
+                       npad, m->bout[0], m->bout[1], d_prob, d_cls);
     HIP_TRY(hipGetLastError());
     if (m->profile) {
         HIP_TRY(hipEventRecord(e1, m->stream));
@@ -944,7 +507,6 @@ int predict_common(dm_model* m, const float* x, long long xstride, int64_t x_flo
 }
 
 int model_init(dm_model* m, const float* weights) {
-    using namespace lstm32;
     HIP_TRY(hipSetDevice(m->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, m->device));
@@ -954,7 +516,7 @@ int model_init(dm_model* m, const float* weights) {
     m->grid_cap = m->num_cu;  // 120 KB of LDS per workgroup -> one resident (persistent) workgroup per CU
     HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     m->host_weights.assign(weights, weights + DM_WEIGHT_FLOATS);
-    Packed P = pack_weights(weights);
+    Packed32 P = dmk::pack_weights_f32(weights);
     m->bout[0] = P.bout[0];
     m->bout[1] = P.bout[1];
     HIP_TRY(hipMalloc(&m->d_wpack, P.w.size() * sizeof(float)));
@@ -963,15 +525,14 @@ int model_init(dm_model* m, const float* weights) {
     HIP_TRY(hipMemcpy(m->d_wpack, P.w.data(), P.w.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_bpack, P.b.data(), P.b.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_hpack, P.h.data(), P.h.size() * sizeof(float), hipMemcpyHostToDevice));
-    size_t scratch_bytes = size_t(m->grid_cap) * SCRATCH_FLOATS_PER_WG * sizeof(float);      // h sequences of the fp32 kernel
+    size_t scratch_bytes = size_t(m->grid_cap) * dmk::f32_scratch_floats_per_wg() * sizeof(float);      // h sequences of the fp32 kernel
     HIP_TRY(hipMalloc(&m->d_scratch, scratch_bytes));
     HIP_TRY(hipMemsetAsync(m->d_scratch, 0, scratch_bytes, m->stream));      // ordered with the launches of m->stream (non-blocking)
 #if defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2)
-    HIP_TRY(hipMalloc(&m->d_dbg, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(m->d_dbg, 0, size_t(m->grid_cap) * WAVES * 8 * sizeof(unsigned long long), m->stream));
+    HIP_TRY(hipMalloc(&m->d_dbg, size_t(m->grid_cap) * dmk::f32_waves() * 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(m->d_dbg, 0, size_t(m->grid_cap) * dmk::f32_waves() * 8 * sizeof(unsigned long long), m->stream));
 #endif
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_f32_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_BYTES)));
+    HIP_TRY(dmk::f32_prepare());
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->range_flag), sizeof(int) * dm_model::RANGE_SLOTS, hipHostMallocMapped));
     for (int i = 0; i < dm_model::RANGE_SLOTS; ++i) {
         m->range_flag[i] = 0;
@@ -981,7 +542,7 @@ int model_init(dm_model* m, const float* weights) {
     m->range_cur = 0;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_range_flag), m->range_flag, 0));
     {   // trained kernels far outside the usual range cannot be split into f16 halves: such a model runs the fp32 kernel
-        Packed16 P16 = pack_weights_tile(weights);
+        Packed16 P16 = dmk::pack_weights_f16s(weights);
         m->f16_ok = P16.finite && P16.max_abs <= 65504.0f;
         m->f16_max_abs = P16.finite ? P16.max_abs : INFINITY;
         m->len_shift = P16.len_shift;
@@ -1218,7 +779,7 @@ int dm_predict_read_at(dm_model* m, const float* rows, int64_t m_rows, const int
 // debug builds (-DDM_TIMING): copy the per-wave section cycle counters [grid][waves][8]; returns element count
 extern "C" long long dm_debug_timing(dm_model* m, unsigned long long* out, long long cap) {
     if (!m || !m->d_dbg) return 0;
-    const long long n = (long long)m->grid_cap * lstm32::WAVES * 8;
+    const long long n = (long long)m->grid_cap * dmk::f32_waves() * 8;
     if (out && cap >= n) (void)hipMemcpy(out, m->d_dbg, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     return n;
 }
@@ -1738,6 +1299,7 @@ typedef int (*fn_reduce)(const void*, void*, size_t, int, int, int, void*, hipSt
 typedef int (*fn_reducescatter)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
+typedef int (*fn_group)(void);
 struct Rccl {
     void* h = nullptr;
     fn_getid getid = nullptr;
@@ -1747,6 +1309,7 @@ struct Rccl {
     fn_reducescatter reducescatter = nullptr;
     fn_destroy destroy = nullptr;
     fn_errstr errstr = nullptr;
+    fn_group group_start = nullptr, group_end = nullptr;      // optional: one launch for the three counter arrays of a reduce-scatter
 };
 Rccl g_rccl;
 constexpr int NCCL_INT32 = 2, NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_MAX = 2;   // ncclDataType_t / ncclRedOp_t values
@@ -1767,6 +1330,8 @@ int load_rccl() {
     g_rccl.reducescatter = (fn_reducescatter)dlsym(h, "ncclReduceScatter");
     g_rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
     g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+    g_rccl.group_start = (fn_group)dlsym(h, "ncclGroupStart");
+    g_rccl.group_end = (fn_group)dlsym(h, "ncclGroupEnd");
     if (!g_rccl.getid || !g_rccl.init || !g_rccl.allreduce || !g_rccl.reduce || !g_rccl.destroy)
         return fail(DM_ERCCL, "librccl is missing required symbols");
     g_rccl.h = h;
@@ -1931,12 +1496,23 @@ int dm_summary_reduce_scatter(dm_summary* s, dm_comm* c, int64_t* first, int64_t
         HIP_TRY(hipMalloc(&s->d_slice, sizeof(int) * 3 * chunk));
         s->slice_chunk = chunk;
     }
-    for (int k = 0; k < 3; ++k) {
+    // the three counter arrays as ONE group where librccl has the group calls (one fused launch per rank instead of three)
+    const bool grouped = g_rccl.group_start && g_rccl.group_end;
+    if (grouped) {
+        int e = g_rccl.group_start();
+        if (e) return fail(DM_ERCCL, "ncclGroupStart: %s", rccl_err(e));
+    }
+    int err = 0;
+    for (int k = 0; k < 3 && !err; ++k) {
         // the send buffer of array k is read up to nranks * chunk <= length + nranks - 1 positions: past `length` that is the head of
         // the next array (or the allocation's slack) - sums of positions that do not exist, never looked at
-        int e = g_rccl.reducescatter(s->d_counts + k * s->length, s->d_slice + k * s->slice_chunk, size_t(chunk), NCCL_INT32, NCCL_SUM, c->comm, c->stream);
-        if (e) return fail(DM_ERCCL, "ncclReduceScatter: %s", rccl_err(e));
+        err = g_rccl.reducescatter(s->d_counts + k * s->length, s->d_slice + k * s->slice_chunk, size_t(chunk), NCCL_INT32, NCCL_SUM, c->comm, c->stream);
     }
+    if (grouped) {
+        const int e = g_rccl.group_end();              // always closed, also after a failed call inside the group
+        if (!err) err = e;
+    }
+    if (err) return fail(DM_ERCCL, "ncclReduceScatter: %s", rccl_err(err));
     HIP_TRY(hipStreamSynchronize(c->stream));
     ++c->reduces;
     c->reduced_bytes += int64_t(3) * s->length * 4;

@@ -1,0 +1,215 @@
+// kern_f16s.hip - translation unit of lstm16s::bilstm_f16s_kernel<0 | 1> (the 32x32 MFMA forms of DM_PREC_F16X3 / DM_PREC_F16I8; and, in an
+// experiment build, the roles kernel): the kernels, their weight packer, their launch wrapper.
+#include "kernels.h"
+#include <utility>
+#include "lstm_f16s.hip.inc"
+#ifdef DM_WITH_F16X3_ROLES   // the matrix / cell wave-pair form of the default kernel (round 4): an experiment build, not part of the product
+#include "../../tools/experiments/f16r/lstm_f16r.hip.inc"
+#endif
+
+static_assert(lstm16s::TILE_M == dmk::TILE_M, "work item size");
+
+namespace {
+inline void fill(lstm16s::Params& p, const dmk::F16Args& a) {
+    p.wpack = a.wpack;
+    p.wpack_i8 = a.wpack;
+    p.hpack = a.hpack;
+    p.bout0 = p.bout1 = 0.0f;          // (the head's bias is added by lstmhead::head_finish_kernel)
+    p.x = a.x;
+    p.xstride = a.xstride;
+    p.widx = a.widx;
+    p.n = a.n;
+    p.ntiles = a.ntiles;
+    p.plogit = a.plogit;
+    p.len_scale = std::ldexp(1.0f, -a.len_shift);
+    p.len_mul = std::ldexp(1.0f, a.len_shift);
+    p.range_flag = a.range_flag;
+    for (int k = 0; k < 24; ++k) p.i8s[k] = a.i8s ? a.i8s[k] : 0.0f;
+}
+}  // namespace
+
+namespace dmk {
+
+// tile-major split-f16 packing (lstm_f16s.hip.inc): [dir][layer][tile][k16-step][hi|lo][lane][8 x f16].
+// A-operand lane l of record (tile T, k16-step t): gate row m = l % 32 -> unit 8T + m / 4, gate m % 4;
+// k = (half = l / 32, j = 0..7) -> K slot of the B operand the kernel builds in registers:
+//   t < 6 : own unit 8 (2t + j/4) + 2 (j%4) + half
+//   t == 6: j < 4: own unit 96 + 2j + half (slot 100 = the constant 1.0 -> bias row; 101..103 zero);
+//           j >= 4: layer 0: feature 2 (j-4) + half (7 = event length x 2^-len_shift); layers 1, 2: input unit 96 + 2 (j-4) + half
+//   t > 6 : input unit 8 (2 (t-7) + j/4) + 2 (j%4) + half
+// int8 = true (DM_PREC_F16I8): the second KB of a record holds, instead of the lo f16 halves, the int8 cross-term weights of the
+// same 16 K slots: bytes (2j, 2j + 1) of lane l = (w_hi8, w_lo8) of the unit of slot j - they meet the B bytes (lo8, hi8) of that
+// unit in one v_mfma_i32_32x32x32_i8.  Scales, per (direction, layer, gate kind g): sw = max(|w_hi|, 2^12 |w_lo|) over the gate's
+// rows; w_hi8 = rint(127 w_hi / sw), w_lo8 = rint(127 * 2^12 w_lo / sw); with lo8 = rint(127 * 2^12 h_lo) and hi8 = rint(127 h) one
+// count of the int32 accumulator is i8s = sw 2^-12 / 127^2 pre-activation units for both slots.  Layer 0's mixed k16-step
+// (t = 6: own units 96..99, bias slot, RAW features) keeps its f16 lo record: the kernel runs it with three f16 products.
+// (An int32 accumulator cannot overflow: 2 * 208 slots * 127 * 127 < 2^23.)
+#ifndef DM_WLO_TRUNC_DEFAULT
+#define DM_WLO_TRUNC_DEFAULT 0
+#endif
+#include <cstdlib>
+// lo half of a weight with its low m mantissa bits rounded away (round to nearest even on the bit pattern; m = 0: unchanged)
+static inline _Float16 round_lo_bits(_Float16 lo, int m) {
+    if (m <= 0) return lo;
+    unsigned short b;
+    std::memcpy(&b, &lo, 2);
+    const unsigned short sign = b & 0x8000u;
+    unsigned mag = b & 0x7FFFu;
+    const unsigned half = 1u << (m - 1), lsb = (mag >> m) & 1u;
+    mag = (mag + half - 1u + lsb) & ~((1u << m) - 1u);      // a carry into the exponent is the right value (next binade)
+    if (mag >= 0x7C00u) mag = 0x7BFFu & ~((1u << m) - 1u);
+    b = (unsigned short)(sign | mag);
+    std::memcpy(&lo, &b, 2);
+    return lo;
+}
+// The operand-toggle dial of round 4 (profiles/r04/lo_trunc_dial.txt: closed, not adopted - already m = 3 leaves the 3e-5 bar for a
+// change of arithmetic and returns < 1.5 %).  The product packs full lo halves; only an experiment build (-DDM_WLO_TRUNC_ENV,
+// tools/lo_trunc_dial.py) reads the knob from the environment.
+static int wlo_trunc_bits() {
+#ifdef DM_WLO_TRUNC_ENV
+    const char* e = std::getenv("DM_WLO_TRUNC");
+    if (e && *e) {
+        const int m = std::atoi(e);
+        return m < 0 ? 0 : (m > 9 ? 9 : m);
+    }
+#endif
+    return DM_WLO_TRUNC_DEFAULT;
+}
+
+Packed16 pack_weights_f16s(const float* flat, const bool int8, float* i8s) {
+    using namespace lstm16s;
+    const int wlo_m = int8 ? 0 : wlo_trunc_bits();
+    Packed16 P;
+    P.w.assign(WEIGHT_BYTES, 0);
+    P.len_shift = choose_len_shift(flat);
+    const float len_mul = std::ldexp(1.0f, P.len_shift);
+    const float* p = flat;
+    for (int d = 0; d < 2; ++d) {
+        size_t off = size_t(d) * WEIGHT_BYTES_DIR;
+        for (int l = 0; l < 3; ++l) {
+            const int kin = l == 0 ? NFEAT : HID;
+            const int nks = l == 0 ? KS_L0 : KS_L12;
+            const float* kern = p;
+            const float* bias = p + size_t(kin + HID) * 400;
+            p += size_t(kin + HID) * 400 + 400;
+            float sw[4] = {0.f, 0.f, 0.f, 0.f};
+            constexpr float MAGIC = 0.0f;     // (a bias-row offset for accumulators that would not start from 0: none)
+            // value of (TF kernel row krow | bias row = kin + HID, gate column gc) as the int8 pack stores it
+            auto packed_value = [&](int krow, int gc, const float* swp) {
+                if (krow < kin + HID) return kern[size_t(krow) * 400 + gc] * gate_scale(gc);
+                return (bias[gc] + (gc / 100 == 2 ? 1.0f : 0.0f)) * gate_scale(gc) - (int8 ? swp[gc / 100] / (4096.0f * 127.0f * 127.0f) * MAGIC : 0.0f);
+            };
+            if (int8) {      // every value that rides the int8 product: the recurrent rows, layers 1, 2 also the input rows, the bias row
+                for (int gk = 0; gk < 4; ++gk) {
+                    float m = 0.0f;
+                    for (int u = 0; u < HID; ++u)
+                        for (int krow = (l == 0 ? NFEAT : 0); krow <= kin + HID; ++krow) {
+                            const float v = packed_value(krow, gk * 100 + u, sw);     // (bias offset of sw = 0: the loop below settles it)
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)(v - (float)hi);
+                            m = std::max(m, std::max(std::fabs((float)hi), 4096.0f * std::fabs((float)lo)));
+                        }
+                    sw[gk] = m > 0.0f ? m : 1.0f;
+                    for (int tries = 0; tries < 64; ++tries) {        // representable with this sw, and no row can leave (-2^22, 2^22)?
+                        bool ok = true;
+                        for (int u = 0; u < HID && ok; ++u) {
+                            double worst = 0.0;
+                            for (int krow = (l == 0 ? NFEAT : 0); krow <= kin + HID; ++krow) {
+                                const float v = packed_value(krow, gk * 100 + u, sw);
+                                const _Float16 hi = (_Float16)v;
+                                const _Float16 lo = (_Float16)(v - (float)hi);
+                                const float qh = std::fabs((float)hi) * 127.0f / sw[gk], ql = std::fabs((float)lo) * 4096.0f * 127.0f / sw[gk];
+                                if (qh > 127.0f || ql > 127.0f) ok = false;
+                                worst += 127.0 * (std::nearbyint(std::min(qh, 127.0f)) + std::nearbyint(std::min(ql, 127.0f)));
+                            }
+                            (void)worst;
+                        }
+                        if (ok) break;
+                        sw[gk] *= 1.125f;
+                    }
+                    if (i8s) i8s[(d * 3 + l) * 4 + gk] = sw[gk] / (4096.0f * 127.0f * 127.0f);
+                }
+            }
+            for (int T = 0; T < NTILE; ++T)
+                for (int t = 0; t < nks; ++t) {
+                    _Float16* dst = reinterpret_cast<_Float16*>(P.w.data() + off);
+                    signed char* dst8 = reinterpret_cast<signed char*>(P.w.data() + off + REC_BYTES / 2);
+                    const bool rec8 = int8 && !(l == 0 && t == 6);
+                    off += REC_BYTES;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int m = lane & 31, half = lane >> 5;
+                        const int unit = 8 * T + m / 4, gate = m % 4;
+                        for (int j = 0; j < 8; ++j) {
+                            float v = 0.0f;
+                            if (unit < HID) {
+                                const int gc = gate * 100 + unit;
+                                int krow = -1;          // row of the TF kernel; -2 = bias row; -1 = zero
+                                float mul = 1.0f;
+                                if (t < 6 || (t == 6 && j < 4)) {                       // own hidden state
+                                    const int u = t < 6 ? 8 * (2 * t + j / 4) + 2 * (j % 4) + half : 96 + 2 * j + half;
+                                    if (u < HID) krow = kin + u;
+                                    else if (u == HID) krow = -2;
+                                } else if (t == 6) {
+                                    const int f = 2 * (j - 4) + half;
+                                    if (l == 0) {
+                                        if (f < NFEAT) krow = f;
+                                        else {
+                                            krow = NFEAT - 1;
+                                            mul = len_mul;
+                                        }
+                                    } else if (96 + f < HID) krow = 96 + f;
+                                } else {
+                                    const int u = 8 * (2 * (t - 7) + j / 4) + 2 * (j % 4) + half;
+                                    if (u < HID) krow = u;
+                                }
+                                if (krow >= 0) v = kern[size_t(krow) * 400 + gc] * gate_scale(gc) * mul;
+                                else if (krow == -2) v = packed_value(kin + HID, gc, sw);        // bias + forget_bias (int8 pack: - i8s * MAGIC)
+                            }
+                            if (!std::isfinite(v)) P.finite = false;
+                            else P.max_abs = std::max(P.max_abs, std::fabs(v));
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)(v - (float)hi);
+                            dst[(0 * 64 + lane) * 8 + j] = hi;
+                            if (!rec8) dst[(1 * 64 + lane) * 8 + j] = round_lo_bits(lo, wlo_m);
+                            else {
+                                const float s8 = 127.0f / sw[gate];
+                                const float qh = std::nearbyint((float)hi * s8), ql = std::nearbyint((float)lo * s8 * 4096.0f);
+                                dst8[lane * 16 + 2 * j] = (signed char)std::max(-127.0f, std::min(127.0f, qh));
+                                dst8[lane * 16 + 2 * j + 1] = (signed char)std::max(-127.0f, std::min(127.0f, ql));
+                            }
+                        }
+                    }
+                }
+        }
+    }
+    return P;
+}
+
+
+hipError_t f16s_prepare(int mm) {
+    if (mm == 0) return hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16s::bilstm_f16s_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16s::LDS_BYTES));
+    if (mm == 1) return hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16s::bilstm_f16s_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16s::LDS_BYTES));
+#ifdef DM_WITH_F16X3_ROLES
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16r::bilstm_f16r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16r::LDS_BYTES_R));
+#else
+    return hipErrorInvalidValue;
+#endif
+}
+void f16s_launch(int mm, const F16Args& a, int grid, hipStream_t stream) {
+    lstm16s::Params p;
+    fill(p, a);
+    if (mm == 0) hipLaunchKernelGGL(lstm16s::bilstm_f16s_kernel<0>, dim3(grid), dim3(lstm16s::THREADS), lstm16s::LDS_BYTES, stream, p);
+    else if (mm == 1) hipLaunchKernelGGL(lstm16s::bilstm_f16s_kernel<1>, dim3(grid), dim3(lstm16s::THREADS), lstm16s::LDS_BYTES, stream, p);
+#ifdef DM_WITH_F16X3_ROLES
+    else hipLaunchKernelGGL(lstm16r::bilstm_f16r_kernel, dim3(grid), dim3(lstm16r::THREADS_R), lstm16r::LDS_BYTES_R, stream, p);
+#endif
+}
+bool f16s_has_roles() {
+#ifdef DM_WITH_F16X3_ROLES
+    return true;
+#else
+    return false;
+#endif
+}
+
+}  // namespace dmk

@@ -59,12 +59,13 @@ EXTRA = sys.argv[3:] if len(sys.argv) > 3 else []
 
 def build(names):
     os.makedirs(ABL, exist_ok=True)
-    src = os.path.join(ROOT, "deepmod_amd", "csrc", "deepmod_hip.hip")
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
     for name in names:
         out = os.path.join(ABL, "lib_%s.so" % name)
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-mllvm", "-amdgpu-mfma-vgpr-form", "-o", out, src,
-               "-ldl"] + VARIANTS[name] + (["-DDM_EXPERIMENT"] if VARIANTS[name] else [])      # any switch needs the umbrella (deepmod_hip.hip: a stray -D is a compile error)
-        subprocess.check_call(cmd, cwd=os.path.dirname(src))
+        # any switch needs the umbrella (csrc/kernels.h: a stray -D is a compile error); one object directory per variant
+        flags = VARIANTS[name] + (["-DDM_EXPERIMENT"] if VARIANTS[name] else [])
+        ge.build_library(out, flags, objdir=os.path.join(ABL, "obj_" + name), quiet=True)
         print("built", out)
 
 

@@ -40,15 +40,16 @@ def required_wait_states(opcode: str) -> int:
     return passes + (4 if xdl else 2)
 
 
-def extract_code_object(lib: str, workdir: str) -> str:
-    """-> path of the gfx950 code object embedded in `lib` (llvm-objdump writes the bundles next to its input: work on a copy)."""
+def extract_code_objects(lib: str, workdir: str) -> list:
+    """-> paths of the gfx950 code objects embedded in `lib`, one per translation unit (llvm-objdump writes the bundles next to its input:
+    work on a copy)."""
     local = os.path.join(workdir, "lib.so")
     shutil.copy(lib, local)
     subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, capture_output=True)
-    for f in sorted(os.listdir(workdir)):
-        if "amdgcn" in f and "gfx950" in f:
-            return os.path.join(workdir, f)
-    raise RuntimeError("no gfx950 code object in %s" % lib)
+    out = [os.path.join(workdir, f) for f in sorted(os.listdir(workdir)) if "amdgcn" in f and "gfx950" in f and os.path.getsize(os.path.join(workdir, f)) > 0]
+    if not out:
+        raise RuntimeError("no gfx950 code object in %s" % lib)
+    return out
 
 
 def kernel_metadata(code_object: str) -> dict:
@@ -144,9 +145,10 @@ def lint_kernel(instrs: list) -> dict:
 def report(lib: str = LIB) -> dict:
     tmp = tempfile.mkdtemp(prefix="dm_isa_lint_")
     try:
-        co = extract_code_object(lib, tmp)
-        meta = kernel_metadata(co)
-        dis = disassemble(co)
+        meta, dis = {}, {}
+        for co in extract_code_objects(lib, tmp):
+            meta.update(kernel_metadata(co))
+            dis.update(disassemble(co))
         out = {}
         for short, sym in PRODUCT_KERNELS.items():
             if sym not in dis:

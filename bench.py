@@ -355,10 +355,10 @@ def extras(m, _lib, model, precision, x_dev0, x_host0, prob_dev, cls_dev, reps=4
 E2E_GENOME_LEN, E2E_COVERAGE, E2E_READS_PER_FILE, E2E_CHROM = 4_641_652, 30.0, 100, "NC_000913.3"
 # sha256 of the two BED files the command writes for this input with the default kernel (deterministic: integer counters, a
 # deterministic classifier - lstm16q::bilstm_f16q_kernel; the 32x32x16 kernel of rounds 2-3, DM_F16X3_SHAPE=32, gives a3c49283... / d065fd60...:
-# a different summation order moves a few near-tie windows; profiles/r04/bench_f16x3.json; round 5's merged mixed k32-step changed the "+" digest
-# from c95a6b53... for the same reason - the "-" strand kept its bytes).  A different digest = different BED bytes.
-E2E_EXPECTED_BED_SHA256 = {"+": "dabebff6b9addd8e1d3f5f67412c33ca19ff0b61e179890e57987585614b1d61",
-                            "-": "4775978f0ebefea6ecc55e18c0d6bf0f86b790b813352a56fb514f5da5395f0f"}
+# a different summation order moves a few near-tie windows; profiles/r04/bench_f16x3.json; round 5's merged mixed k32-step and the event-length cut of
+# DESIGN 4.1' changed both from c95a6b53... / 4775978f... for the same reason).  A different digest = different BED bytes.
+E2E_EXPECTED_BED_SHA256 = {"+": "595d1000010ff8262440eadadf44eb98aa0c10511cff7bfef973cb24bba39715",
+                            "-": "007c2a59d6fe0d3d8b5b55f2acb88e48a087aac3a3b9b8029d5298a1c1079071"}
 
 
 def _e2e_gen(args):

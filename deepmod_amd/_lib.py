@@ -105,6 +105,9 @@ SIGNATURES = [
     ("dm_rows_add_mapped", _c.c_int, [_vp, _i64, _i64, _i64, _c.c_int32] + [_vp] * 16),
     ("dm_rows_info", _i64, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64), _vp, _vp, _i64, _c.POINTER(_i64)]),
     ("dm_rows_emit", _i64, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32)]),
+    ("dm_rows_device_info", _c.c_int, [_vp, _c.POINTER(_i64), _c.POINTER(_i64)]),
+    ("dm_rows_emit_device", _i64, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32)]),
+    ("dm_rows_assemble", _c.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64]),
 ]
 
 

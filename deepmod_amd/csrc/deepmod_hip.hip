@@ -55,6 +55,35 @@ bool is_device_ptr(const void* p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// feature rows of raw reads, assembled on the device (round 5; get_Feature, myDetect.py:839-903, fnum = 7): row q of the batch = one-hot of
+// its reference base | mean, stdv, length of the event it shows - from the device form of rowsbatch.inc (ev3, code, rdesc).  HBM-bound:
+// 13 B in, 28 B out per row; one thread per row, the read of a row found by binary search over the (few hundred) read descriptors.
+// ---------------------------------------------------------------------------------------------
+__global__ void rows_assemble_kernel(float* __restrict__ rows, const unsigned char* __restrict__ code, const float* __restrict__ ev3,
+                                     const long long* __restrict__ rdesc, const int n_reads, const long long n_rows) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_rows) return;
+    int lo = 0, hi = n_reads - 1;                    // the last read whose first row is <= q
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rdesc[4 * (long long)mid] <= q) lo = mid;
+        else hi = mid - 1;
+    }
+    const long long* d = rdesc + 4 * (long long)lo;
+    const long long e = q + d[1];
+    const bool has = e >= d[2] && e < d[3];
+    const unsigned c = code[q];
+    float* o = rows + q * DM_NFEAT;
+    o[0] = c == 0u ? 1.0f : 0.0f;
+    o[1] = c == 1u ? 1.0f : 0.0f;
+    o[2] = c == 2u ? 1.0f : 0.0f;
+    o[3] = c == 3u ? 1.0f : 0.0f;
+    o[4] = has ? ev3[3 * e] : 0.0f;
+    o[5] = has ? ev3[3 * e + 1] : 0.0f;
+    o[6] = has ? ev3[3 * e + 2] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // summary kernel: dense int32 counters with a wavefront-level pre-reduction.
 // Bases arrive read by read, so a wave mostly sees 64 consecutive distinct positions (one atomic per
 // counter per base), but deep pile-ups (amplicons, the cov > 1000 case of the BED format) put long
@@ -894,6 +923,18 @@ int dm_model_calibrate_i8(dm_model* m, int64_t n_windows, double bound, double* 
         (void)hipFree(m->d_wpack16qi);
         m->d_wpack16i = m->d_wpack16qi = nullptr;
     }
+    return DM_OK;
+}
+
+// device form of a raw batch (dm_rows_emit_device) -> feature rows [n_rows][7] on the device, queued on the model's stream
+int dm_rows_assemble(dm_model* m, float* d_rows, const uint8_t* d_code, const float* d_ev3, const int64_t* d_rdesc, int64_t n_reads, int64_t n_rows) {
+    if (!m) return fail(DM_EINVAL, "null model");
+    if (n_rows <= 0) return DM_OK;
+    if (!d_rows || !d_code || !d_ev3 || !d_rdesc || n_reads <= 0 || n_reads > 0x7fffffffLL) return fail(DM_EINVAL, "dm_rows_assemble: null array or no read");
+    HIP_TRY(hipSetDevice(m->device));
+    hipLaunchKernelGGL(rows_assemble_kernel, dim3(unsigned((n_rows + 255) / 256)), dim3(256), 0, m->stream, d_rows, d_code, d_ev3,
+                       reinterpret_cast<const long long*>(d_rdesc), int(n_reads), (long long)n_rows);
+    HIP_TRY(hipGetLastError());
     return DM_OK;
 }
 

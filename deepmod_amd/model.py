@@ -214,6 +214,10 @@ class BiLSTMModel:
         """dm_predict_read_at on raw device addresses: only the windows centred on the given rows."""
         _lib.check(self._lib.dm_predict_read_at(self._h, rows_ptr, m_rows, centre_ptr, count, prob_ptr, cls_ptr))
 
+    def assemble_rows_device(self, rows_ptr: int, code_ptr: int, ev3_ptr: int, rdesc_ptr: int, n_reads: int, n_rows: int):
+        """dm_rows_assemble on raw device addresses: the device form of a batch of raw reads -> feature rows [n_rows][7], on the model's stream."""
+        _lib.check(self._lib.dm_rows_assemble(self._h, rows_ptr, code_ptr, ev3_ptr, rdesc_ptr, n_reads, n_rows))
+
     def predict_read_at(self, rows, centres, prob=None, cls=None, want_prob: bool = True):
         """Classify the windows centred on rows[centres[i]] of a feature matrix rows float[m,7] (numpy or DeviceArray)."""
         if isinstance(rows, DeviceArray):

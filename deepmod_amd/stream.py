@@ -39,10 +39,27 @@ HALF = 10          # windowsize // 2
 
 class Prepared:
     """One worker batch, ready for the device.  Rows of the reads are concatenated, reads grouped by (contig, strand)."""
-    __slots__ = ('rows', 'pos', 'flags', 'n_rows', 'groups', 'n_windows', 'n_reads', 'errors', 'contig_len', 'timing', 'files', 'on_done', 'f32', 'sel')
+    __slots__ = ('_rows', 'pos', 'flags', 'n_rows', 'groups', 'n_windows', 'n_reads', 'errors', 'contig_len', 'timing', 'files', 'on_done', 'f32', 'sel',
+                 'ev3', 'code', 'rdesc')
+
+    @property
+    def rows(self):
+        """Feature rows [n_rows][7].  A batch in the device form (ev3 / code / rdesc, see below) has none on the host: a consumer that asks
+        for them anyway (the CPU backend of the tests, a comparison) gets the host restatement of dm_rows_assemble."""
+        if self._rows is None and self.ev3 is not None:
+            return assemble_rows(self.ev3, self.code, self.rdesc, self.n_rows)
+        return self._rows
+
+    @rows.setter
+    def rows(self, value):
+        self._rows = value
 
     def __init__(self):
-        self.rows = np.zeros((0, 7), np.float32)
+        self._rows = np.zeros((0, 7), np.float32)
+        # device form of a batch of raw reads (round 5, rowsbatch.inc dm_rows_emit_device): ev3 f32[E][3] = (mean, stdv, length) of the events the rows
+        # show, code u8[n_rows] = one-hot class of a row (255: none), rdesc i64[reads][4] = (first row, row -> event shift, first event, end event);
+        # `rows` is then built on the device (HipBackend.submit -> dm_rows_assemble): 13 instead of 28 bytes per row cross the host and PCIe
+        self.ev3 = self.code = self.rdesc = None
         self.pos = np.zeros(0, np.int64)          # [n_rows classified rows | extra rows]
         self.flags = np.zeros(0, np.uint8)
         self.n_rows = 0
@@ -59,6 +76,24 @@ class Prepared:
         self.files: List[str] = []
         self.f32 = False             # a feature outside the split-f16 kernel's range (or NaN): this batch runs the fp32 kernel
         self.on_done = None          # called once the device has consumed the host arrays (a feeder slot goes back to its queue)
+
+
+def assemble_rows(ev3: np.ndarray, code: np.ndarray, rdesc: np.ndarray, n_rows: int) -> np.ndarray:
+    """Host restatement of dm_rows_assemble (deepmod_hip.hip rows_assemble_kernel): the device form of a raw batch -> rows [n_rows][7] =
+    one-hot of the row's reference base | mean, stdv, length of the event it shows (get_Feature, myDetect.py:839-903)."""
+    rows = np.zeros((n_rows, 7), np.float32)
+    if n_rows == 0:
+        return rows
+    code = np.asarray(code[:n_rows])
+    for c in range(4):
+        rows[code == c, c] = 1.0
+    rdesc = np.asarray(rdesc, np.int64).reshape(-1, 4)
+    q = np.arange(n_rows, dtype=np.int64)
+    r = np.searchsorted(rdesc[:, 0], q, side='right') - 1          # the last read whose first row is <= q
+    e = q + rdesc[r, 1]
+    has = (e >= rdesc[r, 2]) & (e < rdesc[r, 3])
+    rows[has, 4:7] = np.asarray(ev3, np.float32).reshape(-1, 3)[e[has]]
+    return rows
 
 
 def rows_from_packed(pk: Dict, base: str, src: str, out: Prepared) -> None:
@@ -429,8 +464,24 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
         out.n_reads = int(ok.sum())
         out.n_windows = int(info[:nreads, 3][ok].sum())
         out.n_rows = R
+        # device form (round 5): a batch of raw reads only hands over (mean, stdv, length) per event, a class byte per row and a descriptor per
+        # read; the [R][7] matrix is built on the device.  moptions['rows_on_device'] = False / DEEPMOD_ROWS_ON_DEVICE=0: rows on the host as before
+        dev_form = None
+        if R and compact and bool(moptions.get('rows_on_device', os.environ.get('DEEPMOD_ROWS_ON_DEVICE', '1') != '0')):
+            ne, nr = ctypes.c_int64(), ctypes.c_int64()
+            if lib.dm_rows_device_info(h, ctypes.byref(ne), ctypes.byref(nr)) == 1:
+                dev_form = (int(ne.value), int(nr.value))
         if R:
-            if alloc is not None:
+            if dev_form is not None:
+                E, NR = dev_form
+                if alloc is not None:
+                    out.ev3, out.code, out.rdesc, out.pos, out.flags, sel = alloc(R, T, S, dev=dev_form)
+                    out.sel = sel if S else np.zeros(0, np.int32)
+                else:
+                    out.ev3, out.code, out.rdesc = np.empty((max(E, 1), 3), np.float32), np.empty(R, np.uint8), np.empty((NR, 4), np.int64)
+                    out.pos, out.flags, out.sel = np.empty(T, np.int64), np.empty(T, np.uint8), np.empty(S, np.int32)
+                out.rows = None
+            elif alloc is not None:
                 got = alloc(R, T, S) if compact else alloc(R, T)
                 out.rows, out.pos, out.flags = got[:3]
                 out.sel = (got[3] if S else np.zeros(0, np.int32)) if compact else None
@@ -445,8 +496,13 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
             in_range = ctypes.c_int32(1)
             sel_dummy = np.zeros(1, np.int32)
             sel_ptr = (out.sel.ctypes.data if S else sel_dummy.ctypes.data) if compact else None
-            ng = lib.dm_rows_emit(h, rank.ctypes.data, out.rows.ctypes.data, sel_ptr, out.pos.ctypes.data, out.flags.ctypes.data, groups.ctypes.data,
-                                  len(groups), clen.ctypes.data, len(clen), ctypes.byref(in_range))
+            if dev_form is not None:
+                ng = lib.dm_rows_emit_device(h, rank.ctypes.data, out.ev3.ctypes.data, out.code.ctypes.data, out.rdesc.ctypes.data, sel_ptr,
+                                             out.pos.ctypes.data, out.flags.ctypes.data, groups.ctypes.data, len(groups), clen.ctypes.data, len(clen),
+                                             ctypes.byref(in_range))
+            else:
+                ng = lib.dm_rows_emit(h, rank.ctypes.data, out.rows.ctypes.data, sel_ptr, out.pos.ctypes.data, out.flags.ctypes.data, groups.ctypes.data,
+                                      len(groups), clen.ctypes.data, len(clen), ctypes.byref(in_range))
             if ng < 0:
                 raise _lib.DeepModHipError("dm_rows_emit: " + _lib.last_error())
             out.groups = [(names[int(g[0])], '+-'[int(g[1])]) + tuple(int(v) for v in (g[2:8] if compact else g[2:6])) for g in groups[:ng]]
@@ -542,6 +598,27 @@ def _shm_views(buf, n_rows: int, n_pos: int, n_sel: int = 0):
     out = (np.frombuffer(buf, np.float32, n_rows * 7, 0).reshape(n_rows, 7), np.frombuffer(buf, np.int64, n_pos, o_pos),
            np.frombuffer(buf, np.uint8, n_pos, o_flags))
     return out + (np.frombuffer(buf, np.int32, n_sel, o_sel),) if n_sel else out
+
+
+def _shm_layout_dev(n_rows: int, n_pos: int, n_sel: int, n_ev: int, n_reads: int):
+    """byte offsets of the device form [ev3 f32[n_ev][3] | code u8[n_rows] | rdesc i64[n_reads][4] | pos i64[n_pos] | flags u8[n_pos] | sel i32[n_sel]]
+    -> dict(ev3, code, rdesc, pos, flags, sel, end)"""
+    up = lambda v: -(-v // _ALIGN) * _ALIGN
+    o = {'ev3': 0}
+    o['code'] = up(12 * max(n_ev, 1))
+    o['rdesc'] = o['code'] + up(max(n_rows, 1))
+    o['pos'] = o['rdesc'] + up(32 * max(n_reads, 1))
+    o['flags'] = o['pos'] + up(8 * max(n_pos, 1))
+    o['sel'] = o['flags'] + up(max(n_pos, 1))
+    o['end'] = o['sel'] + 4 * max(n_sel, 1)
+    return o
+
+
+def _shm_views_dev(buf, n_rows: int, n_pos: int, n_sel: int, n_ev: int, n_reads: int):
+    o = _shm_layout_dev(n_rows, n_pos, n_sel, n_ev, n_reads)
+    return (np.frombuffer(buf, np.float32, 3 * max(n_ev, 1), o['ev3']).reshape(-1, 3), np.frombuffer(buf, np.uint8, n_rows, o['code']),
+            np.frombuffer(buf, np.int64, 4 * n_reads, o['rdesc']).reshape(n_reads, 4), np.frombuffer(buf, np.int64, n_pos, o['pos']),
+            np.frombuffer(buf, np.uint8, n_pos, o['flags']), np.frombuffer(buf, np.int32, n_sel, o['sel']))
 
 
 def usable_cpus() -> int:
@@ -781,25 +858,27 @@ def feeder_process_main(moptions, work, ready, device: int, shm_dir: str, wid: i
             seq += 1
             holder = {}
 
-            def alloc(n_rows, n_pos, n_sel=0):
-                size = _shm_layout(n_rows, n_pos, n_sel)[2]
+            def alloc(n_rows, n_pos, n_sel=0, dev=None):
+                holder['dev'] = dev
+                size = _shm_layout(n_rows, n_pos, n_sel)[2] if dev is None else _shm_layout_dev(n_rows, n_pos, n_sel, *dev)['end']
+                views = (lambda b: _shm_views(b, n_rows, n_pos, n_sel)) if dev is None else (lambda b: _shm_views_dev(b, n_rows, n_pos, n_sel, *dev))
                 if free_slots is not None and size <= slot_bytes:
                     holder['slot'] = free_slots.get()                    # blocks while the device queue holds every slot
-                    return _shm_views(slot_map(holder['slot']), n_rows, n_pos, n_sel)
+                    return views(slot_map(holder['slot']))
                 fd = os.open(path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
                 try:
                     os.ftruncate(fd, size)
                     holder['mm'] = mmap.mmap(fd, size)
                 finally:
                     os.close(fd)
-                return _shm_views(holder['mm'], n_rows, n_pos, n_sel)
+                return views(holder['mm'])
 
             pb = prepare_batch(moptions, files, normalizer, alloc)
             meta = {'path': path if 'mm' in holder else None, 'slot': holder.get('slot'), 'n_rows': pb.n_rows, 'n_pos': len(pb.pos),
                     'groups': pb.groups, 'n_windows': pb.n_windows, 'n_reads': pb.n_reads, 'errors': {k: list(v) for k, v in pb.errors.items()},
                     'contig_len': dict(pb.contig_len), 'timing': dict(pb.timing), 'files': list(pb.files), 'f32': pb.f32,
-                    'n_sel': None if pb.sel is None else len(pb.sel)}
-            pb.rows = pb.pos = pb.flags = pb.sel = None          # drop the views before a mapping goes away
+                    'n_sel': None if pb.sel is None else len(pb.sel), 'dev': holder.get('dev') if pb.ev3 is not None else None}
+            pb.rows = pb.pos = pb.flags = pb.sel = pb.ev3 = pb.code = pb.rdesc = None          # drop the views before a mapping goes away
             if 'mm' in holder:
                 holder['mm'].close()
             ready.put(meta)
@@ -823,9 +902,12 @@ def prepared_from_shm(meta, slot_buffer=None) -> Prepared:
     pb.files = meta['files']
     pb.f32 = bool(meta.get('f32', False))
     n_sel = meta.get('n_sel')
+    dev = meta.get('dev')
+    mk = (lambda b: _shm_views(b, meta['n_rows'], meta['n_pos'], n_sel or 0)) if dev is None else \
+         (lambda b: _shm_views_dev(b, meta['n_rows'], meta['n_pos'], n_sel or 0, *dev))
     views = None
     if meta.get('slot') is not None:
-        views = _shm_views(slot_buffer(meta['slot']), meta['n_rows'], meta['n_pos'], n_sel or 0)
+        views = mk(slot_buffer(meta['slot']))
     elif meta['path'] is not None:
         fd = os.open(meta['path'], os.O_RDONLY)
         try:
@@ -833,7 +915,12 @@ def prepared_from_shm(meta, slot_buffer=None) -> Prepared:
         finally:
             os.close(fd)
             os.unlink(meta['path'])
-        views = _shm_views(mm, meta['n_rows'], meta['n_pos'], n_sel or 0)
+        views = mk(mm)
+    if views is not None and dev is not None:
+        pb.ev3, pb.code, pb.rdesc, pb.pos, pb.flags = views[:5]
+        pb.rows = None
+        pb.sel = views[5] if n_sel else np.zeros(0, np.int32)
+        return pb
     if views is not None:
         pb.rows, pb.pos, pb.flags = views[:3]
     if n_sel is not None:
@@ -899,8 +986,17 @@ class HipBackend:
             return
         R, T = pb.n_rows, len(pb.pos)
         S = 0 if pb.sel is None else len(pb.sel)
-        o_pos, o_flags, end, o_sel = _shm_layout(R, T, S)
-        o_cls = -(-end // _ALIGN) * _ALIGN
+        dev_form = pb.ev3 is not None              # raw reads in the device form: the feature rows are built on the device (dm_rows_assemble)
+        if dev_form:
+            E, NR = len(pb.ev3), len(pb.rdesc)
+            o = _shm_layout_dev(R, T, S, E, NR)
+            o_pos, o_flags, end, o_sel = o['pos'], o['flags'], o['end'], o['sel']
+            o_rows = -(-end // _ALIGN) * _ALIGN      # device only: nothing is uploaded behind `end`
+            o_cls = o_rows + -(-R * 28 // _ALIGN) * _ALIGN
+        else:
+            o_pos, o_flags, end, o_sel = _shm_layout(R, T, S)
+            o_rows = 0
+            o_cls = -(-end // _ALIGN) * _ALIGN
         n_cls = R if pb.sel is None else max(S, 1)
         t0 = time.perf_counter()
         i = self._k % self.NSET
@@ -908,7 +1004,12 @@ class HipBackend:
         self.model.wait_mark(i)                    # the launches that read this set (batch k - NSET) are done
         t1 = time.perf_counter()
         host, dev = self._staging(self._sets[i], o_cls + n_cls)
-        np.copyto(host.view(np.float32, R * 7).reshape(R, 7), pb.rows, casting='same_kind')
+        if dev_form:
+            np.copyto(host.view(np.float32, 3 * E, o['ev3']).reshape(E, 3), pb.ev3, casting='same_kind')
+            np.copyto(host.view(np.uint8, R, o['code']), pb.code, casting='same_kind')
+            np.copyto(host.view(np.int64, 4 * NR, o['rdesc']).reshape(NR, 4), pb.rdesc, casting='same_kind')
+        else:
+            np.copyto(host.view(np.float32, R * 7).reshape(R, 7), pb.rows, casting='same_kind')
         np.copyto(host.view(np.int64, T, o_pos), pb.pos, casting='same_kind')
         np.copyto(host.view(np.uint8, T, o_flags), pb.flags, casting='same_kind')
         if S:
@@ -920,7 +1021,10 @@ class HipBackend:
         # on the copy stream: the upload of this batch runs while the device classifies the batches before it (nothing queued reads
         # this set: its marker has passed), and the launches below wait for it
         self._lib_check(self._h2d(self.model._h, dev.ptr, host.ptr, end))
-        d_rows, d_pos, d_flags, d_cls, d_sel = dev.ptr, dev.ptr + o_pos, dev.ptr + o_flags, dev.ptr + o_cls, dev.ptr + o_sel
+        d_rows, d_pos, d_flags, d_cls, d_sel = dev.ptr + o_rows, dev.ptr + o_pos, dev.ptr + o_flags, dev.ptr + o_cls, dev.ptr + o_sel
+        if dev_form:
+            self.model.assemble_rows_device(d_rows, dev.ptr + o['code'], dev.ptr + o['ev3'], dev.ptr + o['rdesc'], NR, R)
+            self.timing['rows_on_device'] += R
         if pb.sel is None:
             # classic form: window centred on row r -> cls[r]; rows 0..9 and R-10..R-1 are padding of the first / last read
             classify = lambda: self.model.predict_rows_device(d_rows, R, HALF, R - 2 * HALF, d_cls + HALF)

@@ -396,6 +396,15 @@ int64_t dm_rows_info(dm_rowsbatch* h, int64_t* n_rows, int64_t* n_pos, int64_t* 
 #define DM_ROWS_GROUP 8           /* int64 per group: contig, strand, row_lo, row_hi, xlo, xhi, sel_lo, sel_hi */
 int64_t dm_rows_emit(dm_rowsbatch* h, const int32_t* contig_rank, float* rows, int32_t* sel_row, int64_t* pos, uint8_t* flags,
                      int64_t* groups, int64_t cap_groups, int64_t* contig_len, int64_t n_contig_len, int32_t* in_range);
+/* The DEVICE form of a batch of raw reads (round 5; SURVEY 8f1 "fuse get_Feature's rows into the kernel"): instead of rows [R][7] the host hands over
+ * ev3 [E][3] = (mean, stdv, length) of the events the rows cover, code [R] (one-hot class of a row: 0..3 = A, C, G, T, 255 = none) and rdesc [reads][4]
+ * = (first row, row -> event shift, first event, end event) - 13 instead of 28 bytes per row, no feature row written or range-scanned on the host -
+ * and dm_rows_assemble builds the same [R][7] matrix on the device (get_Feature, myDetect.py:839-903, bit for bit: the values are copied, not computed).
+ * dm_rows_device_info (after dm_rows_info): 1 if every emitted read is a raw read, with the sizes E and reads; dm_rows_emit_device: as dm_rows_emit. */
+int dm_rows_device_info(dm_rowsbatch* h, int64_t* n_events, int64_t* n_reads);
+int64_t dm_rows_emit_device(dm_rowsbatch* h, const int32_t* contig_rank, float* ev3, uint8_t* code, int64_t* rdesc, int32_t* sel_row, int64_t* pos,
+                            uint8_t* flags, int64_t* groups, int64_t cap_groups, int64_t* contig_len, int64_t n_contig_len, int32_t* in_range);
+int dm_rows_assemble(dm_model* m, float* d_rows, const uint8_t* d_code, const float* d_ev3, const int64_t* d_rdesc, int64_t n_reads, int64_t n_rows);
 
 #ifdef __cplusplus
 }

@@ -1,10 +1,12 @@
 """GPU (-m gpu): the staging entry points of the streaming worker (include/deepmod_hip.h: dm_host_alloc / dm_host_free,
 dm_model_h2d_async, dm_model_mark / dm_model_wait_mark): a pipelined sequence of batches through page-locked staging sets gives
 the classes of plain synchronous calls, markers order host and device, and a range violation surfaces at the marker."""
+import os
+
 import numpy as np
 import pytest
 
-from deepmod_amd import _lib, model, synth
+from deepmod_amd import _lib, model, stream, synth, synth_reads
 
 pytestmark = pytest.mark.gpu
 
@@ -135,3 +137,46 @@ def test_streaming_batches_outside_the_f16_range_take_the_fp32_kernel(tmp_path, 
     m.set_precision('f32')
     assert np.array_equal(got, m.predict_read(rows, 10, len(rows) - 20, want_prob=False)[1])
     m.close()
+
+
+def test_rows_assembled_on_the_device_equal_the_host_rows(tmp_path, gpu_device):
+    """Round 5: a batch of raw reads is handed over in the device form - (mean, stdv, length) per event, a
+    class byte per row, a descriptor per read - and dm_rows_assemble builds get_Feature's [R][7] matrix (myDetect.py:839-903) on the device:
+    bit for bit the rows dm_rows_emit writes on the host, from 13 instead of 28 bytes per row; the streaming engine gives the same BED either way."""
+    from deepmod_amd import _lib, model as dm, signal as dmsignal
+    files, fasta = synth_reads.write_synthetic_raw_run(str(tmp_path / 'in'), n_reads=30, reads_per_file=6, genome_len=40000, seed=8, chrom='chrR',
+                                                       min_len=300, max_len=2500)
+    prefix = str(tmp_path / 'model' / 'm')
+    os.makedirs(os.path.dirname(prefix))
+    w = synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)
+    mo = {'fnum': 7, 'hidden': 100, 'windowsize': 21, 'modfile': [prefix, os.path.dirname(prefix) + '/'], 'outFolder': str(tmp_path / 'out'), 'Base': 'C',
+          'Ref': fasta, 'alignStr': 'minimap2', 'region': [[None, None, None]], 'ConUnk': True, 'SignalGroup': 'simple', 'outLevel': 3, 'device': gpu_device}
+    os.makedirs(mo['outFolder'])
+    norm = dmsignal.SignalNormalizer(gpu_device)
+    dev = stream._prepare_batch_c(dict(mo), files, lambda: norm)
+    host = stream._prepare_batch_c(dict(mo, rows_on_device=False), files, lambda: norm)
+    assert dev.ev3 is not None and dev._rows is None and host.ev3 is None and dev.n_rows == host.n_rows > 20000
+    R, E, NR = dev.n_rows, len(dev.ev3), len(dev.rdesc)
+    m = dm.BiLSTMModel(w, device=gpu_device)
+    d_ev3, d_code, d_rdesc = (dm.DeviceArray.from_host(a, gpu_device) for a in (dev.ev3, dev.code, dev.rdesc))
+    d_rows = dm.DeviceArray((R, 7), np.float32, gpu_device)
+    m.assemble_rows_device(d_rows.ptr, d_code.ptr, d_ev3.ptr, d_rdesc.ptr, NR, R)
+    m.sync()
+    got = d_rows.to_host()
+    assert np.array_equal(got.view(np.uint32), host._rows.view(np.uint32))                # the device's rows == the host's rows, bit for bit
+    assert np.array_equal(stream.assemble_rows(dev.ev3, dev.code, dev.rdesc, R).view(np.uint32), got.view(np.uint32))      # == the host restatement
+    assert dev.ev3.nbytes + dev.code.nbytes + dev.rdesc.nbytes < 0.5 * host._rows.nbytes
+    for a in (d_ev3, d_code, d_rdesc, d_rows):
+        a.free()
+    m.close()
+    beds = {}
+    for name, on_dev in (('device', True), ('host', False)):
+        mo2 = dict(mo, rows_on_device=on_dev)
+        backend = stream.HipBackend(mo2, gpu_device)
+        eng = stream.StreamEngine(mo2, backend)
+        eng.run(iter([files[:3], files[3:]]), feeders=1, make_normalizer=lambda: norm)
+        beds[name] = {k: bytes(v) for k, v in eng.finalize(None, None, write=False).items()}
+        assert (backend.timing['rows_on_device'] > 0) == on_dev
+        backend.close()
+    assert beds['device'] == beds['host'] and len(beds['device']) == 2 and all(len(v) > 1000 for v in beds['device'].values())
+    norm.close()

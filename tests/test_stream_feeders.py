@@ -241,7 +241,7 @@ def test_compiled_batch_equals_python_batch_on_feature_and_packed_containers(tmp
         assert (got.flags[got.n_rows:] & 1).all() and len(got.pos) > got.n_rows        # extras exist and are all of the wanted base
 
 
-def test_compiled_batch_equals_python_batch_on_raw_containers(tmp_path):
+def test_compiled_batch_equals_python_batch_on_raw_containers(tmp_path, monkeypatch):
     """dm_events_merge + dm_rows_add_raw (alignment walk, get_Feature rows) against rawreads.getEvent / readmap.map_records /
     features.get_Feature / stream.rows_from_reads, the signal stage served by the oracle on both sides."""
     files, fasta = synth_reads.write_synthetic_raw_run(str(tmp_path / 'in'), n_reads=14, reads_per_file=5, genome_len=30000, seed=6,
@@ -253,8 +253,33 @@ def test_compiled_batch_equals_python_batch_on_raw_containers(tmp_path):
     got = stream._prepare_batch_c(dict(mo), files, lambda: norm)
     ref = stream._prepare_batch_py(dict(mo), files, lambda: norm)
     _same_batch(got, ref)
-    _compact_form_is_the_classic_form_without_the_other_bases(stream._prepare_batch_c(dict(mo, select_base=True), files, lambda: norm), got)
+    dev = stream._prepare_batch_c(dict(mo, select_base=True), files, lambda: norm)
+    _compact_form_is_the_classic_form_without_the_other_bases(dev, got)
     assert got.n_reads >= 12 and got.n_windows > 5000 and got.rows[:, :4].sum() > 0 and got.rows[:, 4:].any()
+    # round 5: a compact batch of raw reads is handed over in the DEVICE form - (mean, stdv, length) per event, a class byte per row, a
+    # descriptor per read - and dm_rows_assemble (here: its host restatement stream.assemble_rows, behind Prepared.rows) rebuilds the
+    # same matrix bit for bit; rows_on_device = False keeps the rows on the host
+    assert dev._rows is None and dev.ev3 is not None and dev.code.shape == (dev.n_rows,) and dev.rdesc.shape == (dev.n_reads, 4)
+    assert dev.ev3.nbytes + dev.code.nbytes + dev.rdesc.nbytes < 0.5 * got.rows.nbytes
+    assert (np.diff(dev.rdesc[:, 0]) > 0).all() and dev.rdesc[0, 0] == 0 and (dev.rdesc[:, 3] >= dev.rdesc[:, 2]).all()
+    host = stream._prepare_batch_c(dict(mo, select_base=True, rows_on_device=False), files, lambda: norm)
+    assert host.ev3 is None and np.array_equal(host._rows, got.rows) and np.array_equal(host.sel, dev.sel) and np.array_equal(host.pos, dev.pos)
+    assert host.f32 == dev.f32 == got.f32
+    # ... and through a feeder process' shared-memory hand-over (the process body run here, its signal stage served by the oracle)
+    from deepmod_amd import signal as dmsignal
+    monkeypatch.setattr(dmsignal, 'SignalNormalizer', lambda device: norm)
+    work, ready = queue.Queue(), queue.Queue()
+    work.put((files, 0, 0))
+    shm = str(tmp_path / 'shm_dev')
+    os.makedirs(shm)
+    stream.feeder_process_main(dict(mo, select_base=True), work, ready, 0, shm, 0)
+    meta = ready.get()
+    assert meta is not None and 'failed' not in meta, meta
+    assert meta['dev'] == (len(dev.ev3), dev.n_reads)
+    via = stream.prepared_from_shm(meta)
+    assert via._rows is None and np.array_equal(via.ev3, dev.ev3) and np.array_equal(via.code, dev.code) and np.array_equal(via.rdesc, dev.rdesc)
+    assert np.array_equal(via.rows, got.rows) and np.array_equal(via.sel, dev.sel) and np.array_equal(via.pos, dev.pos) and via.groups == dev.groups
+    assert ready.get() is None and os.listdir(shm) == []
     # a region filter that keeps the first half of the contig only, and a region on another contig (nothing passes)
     for region, expect_some in (([['chrS', None, 15000]], True), ([['chrT', None, None]], False)):
         g2 = stream._prepare_batch_c(dict(mo, region=region), files, lambda: norm)

@@ -9,7 +9,7 @@
 // Every macro below turns a product kernel into a TIMING-ONLY or otherwise experimental build (tools/ablate.py).  None of them may reach
 // the product by accident: without -DDM_EXPERIMENT any of them is a compile error, and dm_build_flags() reports what a library was built with
 // (tests/test_build_guard.py checks the shipped library says "experiment=0").
-#if defined(DM16Q_ABL_NOCELL) || defined(DM16Q_ABL_NODMA) || defined(DM16Q_ABL_MIX1) || defined(DM16Q_ABL_I8T) || defined(DM16Q_ABL_NOBAR) || defined(DM16Q_AINIT) || defined(DM16Q_DEBUG_NOP) ||           \
+#if defined(DM16Q_ABL_NOCELL) || defined(DM16Q_ABL_NODMA) || defined(DM16Q_ABL_MIX1) || defined(DM16Q_ABL_I8T) || defined(DM16Q_ABL_NOBAR) || defined(DM16Q_ABL_NOVMWAIT) || defined(DM16Q_AINIT) || defined(DM16Q_DEBUG_NOP) ||           \
     defined(DM16Q_NOCHUNK) || defined(DM16Q_NOPN) || defined(DM16Q_PRE) || defined(DM16Q_SNAKE) || defined(DM16Q_TRANS_COST) ||                     \
     defined(DM16S_ABL_2PROD) || defined(DM16S_ABL_B64) || defined(DM16S_ABL_LO_ONLY) || defined(DM16S_ABL_MFMA16) ||                              \
     defined(DM16S_ABL_MFMA16_PAD) || defined(DM16S_ABL_NOBAR) || defined(DM16S_ABL_NOCELL) || defined(DM16S_ABL_NODMA) ||                          \

@@ -39,6 +39,7 @@ VARIANTS = {
     "alo6": ["-DDM_WLO_TRUNC_ENV", "-DDM16S_ALO_TRUNC=6"],
     "q_nop0": ["-DDM16Q_NOPN=0"], "q_nop1": ["-DDM16Q_NOPN=1"], "q_nop3": ["-DDM16Q_NOPN=3"], "q_nop7": ["-DDM16Q_NOPN=7"],
     "q_snake": ["-DDM16Q_SNAKE"], "q_pre0": ["-DDM16Q_PRE=0"], "q_pre6": ["-DDM16Q_PRE=6"], "q_snake_pre6": ["-DDM16Q_SNAKE", "-DDM16Q_PRE=6"],
+    "q_novmwait": ["-DDM16Q_ABL_NOVMWAIT"], "q_novmwait_nobar": ["-DDM16Q_ABL_NOVMWAIT", "-DDM16Q_ABL_NOBAR"],      # is the DMA's latency exposed (the wait before the barrier)?
     "q_nobar": ["-DDM16Q_ABL_NOBAR"], "q_nodma": ["-DDM16Q_ABL_NODMA"], "q_nocell": ["-DDM16Q_ABL_NOCELL"], "q_nodma_nobar": ["-DDM16Q_ABL_NODMA", "-DDM16Q_ABL_NOBAR"],      # round 5: where the merged-mixed kernel's time goes (timing only)
     "q_i8t": ["-DDM16Q_ABL_I8T"],        # round 5: timing only - both cross terms of a k32-step as one int8 16x16x64 MFMA (the price of an int8 mode on this shape, before its fold / pack instructions)
     "q_mix1": ["-DDM16Q_ABL_MIX1"],      # round 5: the mixed k32-step issued as one product (timing only)

@@ -8,6 +8,7 @@
 from __future__ import annotations
 
 import mmap
+import re
 import struct
 import zipfile
 from typing import Dict
@@ -29,6 +30,32 @@ class _Cursor:
 
 
 ALIGN = 64
+_HDR = re.compile(rb"^\{'descr': '([^']+)', 'fortran_order': (True|False), 'shape': \(([0-9, ]*)\), \}\s*$")
+
+
+def _fast_header(mm, pos):
+    """(shape, fortran, dtype, data offset) of the .npy image at `pos`, or None: the header numpy itself writes for a plain dtype is one fixed
+    dict literal - parsed with a regular expression instead of ast.literal_eval (20 us per member, eleven members per raw container,
+    a thousand containers per feeder: the safe parser was 5 % of a feeder's time).  Anything else (structured dtypes, foreign writers)
+    goes to numpy's own parser."""
+    if mm[pos:pos + 6] != b'\x93NUMPY':
+        return None
+    major = mm[pos + 6]
+    if major == 1:
+        hlen, start = struct.unpack('<H', mm[pos + 8:pos + 10])[0], pos + 10
+    elif major in (2, 3):
+        hlen, start = struct.unpack('<I', mm[pos + 8:pos + 12])[0], pos + 12
+    else:
+        return None
+    m = _HDR.match(mm[start:start + hlen])
+    if m is None:
+        return None
+    try:
+        dtype = np.dtype(m.group(1).decode('latin1'))
+    except TypeError:
+        return None
+    shape = tuple(int(v) for v in m.group(3).replace(b' ', b'').split(b',') if v)
+    return shape, m.group(2) == b'True', dtype, start + hlen
 
 
 def savez_aligned(file, **arrays) -> None:
@@ -75,12 +102,16 @@ def load(path: str) -> Dict[str, np.ndarray]:
             continue
         n_name, n_extra = struct.unpack('<HH', mm[ho + 26:ho + 30])
         cur = _Cursor(mm, ho + 30 + n_name + n_extra)
-        try:
-            version = npformat.read_magic(cur)
-            shape, fortran, dtype = (npformat.read_array_header_1_0(cur) if version == (1, 0) else npformat.read_array_header_2_0(cur))
-        except Exception:
-            fallback.append(name)
-            continue
+        fast = _fast_header(mm, cur.pos)
+        if fast is not None:
+            shape, fortran, dtype, cur.pos = fast
+        else:
+            try:
+                version = npformat.read_magic(cur)
+                shape, fortran, dtype = (npformat.read_array_header_1_0(cur) if version == (1, 0) else npformat.read_array_header_2_0(cur))
+            except Exception:
+                fallback.append(name)
+                continue
         if dtype.hasobject:
             fallback.append(name)
             continue

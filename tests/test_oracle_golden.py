@@ -52,6 +52,22 @@ def test_oracle_matches_interpreted_reference_graph_on_trained_like_weights():
     assert 0.02 < g["cls"].mean() < 0.98           # both classes occur
 
 
+def test_oracle_matches_interpreted_reference_graph_on_read_shaped_windows():
+    """Round 5: the pin on READ-SHAPED inputs (tests/golden/make_golden_tail.py): 192 windows of synthetic reads whose tail events carry
+    normalised means on the +-5 clip and lengths up to 27,000 samples, evaluated by the reference's serialized graph on the trained-like
+    weights - the kind of input on which the split-f16 kernels had a 2e-5 error no synthetic-window fixture showed (DESIGN 4.1')."""
+    from conftest import trained_like_weights
+    w = trained_like_weights()
+    g = np.load(os.path.join(GOLDEN, "trained_like_tail_case.npz"))
+    X = g["X"]
+    assert X.shape == (192, 21, 7) and X[:, :, 6].max() > 20000 and (np.abs(X[:, :, 4]) == 5.0).any()
+    prob_c, cls_c = oracle_np.predict_windows_c(w, X)
+    assert np.abs(prob_c - g["prob"]).max() <= 5e-6
+    assert np.array_equal(cls_c, g["cls"])
+    prob_n, cls_n, _ = oracle_np.predict_windows_np(w, X)
+    assert np.abs(prob_n - g["prob"]).max() <= 1e-6
+
+
 def test_torch_restatement_equals_c_oracle():
     """oracle/oracle_torch.py (bench.py's cpu_baseline.gemm leg) is the same graph as the C oracle."""
     from oracle import oracle_torch

@@ -593,3 +593,34 @@ def test_selected_mode_on_read_shaped_rows(gpu_device):
     # pre-activations of 10^2..10^3, whose fp32 round-off depends on the summation order), and the default stays within a few 1e-6 of that
     assert worst["f32"] <= 5e-5 and worst["default"] <= worst["f32"] + 1e-5, worst
     m_auto.close(); m_dflt.close(); m_f32.close()
+
+
+def test_one_call_past_two_to_the_31_input_floats(gpu_device):
+    """Maximum sizes: ONE dm_predict_windows call over 15,000,000 windows = 2.2x10^9 input floats (8.8 GB resident in HBM; a 32-bit element
+    index wraps at 14.6 M windows).  The input is 15 copies of one block of 10^6 windows, so the size-independent property is periodicity:
+    every block's probabilities and classes equal block 0's bit for bit (a wrapped index would land 608,732 windows into a block), and
+    block 0 is checked against the oracle on a sample.  All three precisions."""
+    from deepmod_amd import _lib
+    lib = _lib.load()
+    nb, reps = 1_000_000, 15
+    x = synth.synthetic_windows(nb, seed=20260928)
+    w = synth.synthetic_weights(26, 4.0)
+    big = model.DeviceArray((reps * nb, 21, 7), np.float32, gpu_device)
+    for r in range(reps):
+        _lib.check(lib.dm_memcpy_h2d(gpu_device, big.ptr + r * x.nbytes, x.ctypes.data, x.nbytes))
+    assert big.nbytes // 4 > 2 ** 31
+    d_prob = model.DeviceArray((reps * nb, 2), np.float32, gpu_device)
+    d_cls = model.DeviceArray((reps * nb,), np.uint8, gpu_device)
+    pick = np.random.default_rng(3).choice(nb, 2048, replace=False)
+    ref_p, ref_c = oracle_np.predict_windows_c(w, x[pick])
+    for prec, tol in (("f16x3", TOL), ("f32", TOL), ("f16i8", TOL_I8)):
+        m = model.BiLSTMModel(w, device=gpu_device, precision=prec)
+        m.predict_windows(big, prob=d_prob, cls=d_cls)
+        p = d_prob.to_host().reshape(reps, nb, 2)
+        c = d_cls.to_host().reshape(reps, nb)
+        for r in range(1, reps):
+            assert np.array_equal(p[r].view(np.uint32), p[0].view(np.uint32)) and np.array_equal(c[r], c[0]), (prec, r)
+        _check(p[0][pick], c[0][pick], ref_p, ref_c, tol)
+        m.close()
+    for a in (big, d_prob, d_cls):
+        a.free()

@@ -1357,11 +1357,18 @@ constexpr int NCCL_INT32 = 2, NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_MAX = 2;   //
 
 int load_rccl() {
     if (g_rccl.h) return DM_OK;
+    // DEEPMOD_RCCL_LIBRARY names the collective library to bind instead of the system's librccl (a site build of RCCL; the one-GPU test
+    // transport tests/shim/shmccl.cpp).  When it is set nothing else is tried: a wrong path is an error, not a silent fall back.
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
+    const char* named = std::getenv("DEEPMOD_RCCL_LIBRARY");
+    if (named && *named) {
+        h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return fail(DM_ERCCL, "cannot dlopen DEEPMOD_RCCL_LIBRARY=%s: %s", named, dlerror());
+    }
     for (const char* nm : names) {
-        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
+        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!h) return fail(DM_ERCCL, "cannot dlopen librccl: %s", dlerror());
     g_rccl.getid = (fn_getid)dlsym(h, "ncclGetUniqueId");

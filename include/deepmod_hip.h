@@ -235,7 +235,10 @@ int dm_summary_grow(dm_summary* s, int64_t new_length);
  *                       `root` only; root < 0: ncclAllReduce.  All ranks call it with summaries of equal length, in
  *                       the same order.  Integer sums are order independent: the BED is the same for any GPU count.
  *   dm_comm_max_f64 / dm_comm_barrier   small host-synchronous helpers (timing max over ranks, rendezvous)
- *   dm_comm_stats       collectives issued and bytes reduced by this rank so far */
+ *   dm_comm_stats       collectives issued and bytes reduced by this rank so far
+ * The collective library is bound at the first call (dlopen): librccl by soname, or the file DEEPMOD_RCCL_LIBRARY names - a site
+ * build of RCCL, or the shared-memory test transport tests/shim/shmccl.cpp that lets several ranks share one device (RCCL refuses
+ * that), which is how the N > 1 calls below are tested on a one-GPU box.  A path that cannot be loaded is an error (DM_ERCCL). */
 typedef struct dm_comm dm_comm;
 int dm_rccl_unique_id(void* out128);
 dm_comm* dm_comm_create(int device, const void* unique_id128, int rank, int nranks);

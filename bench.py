@@ -227,6 +227,9 @@ def steady_power_leg(m, model, _lib, plog, x_dev0, prob_dev, cls_dev, seconds=1.
     out = plog.summary(t0, t1, skip_s=0.3)
     out["avg_launch_ms"] = ms / max(launches, 1)
     out["launches"] = launches
+    watts = (out.get("socket_power_w") or {}).get("median")
+    if watts and launches:          # the path runs at the board's power limit: time per window = joules per window / what the box allows
+        out["microjoules_per_window"] = 1e3 * watts * out["avg_launch_ms"] / int(x_dev0.shape[0])
     return out
 
 

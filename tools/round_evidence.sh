@@ -21,7 +21,7 @@ python tools/len_error.py > $O/len_error.txt 2>&1
 python tools/isa_lint.py > $O/isa_lint.json 2>&1
 ( cd /tmp && export TMPDIR=/tmp; for C in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/fc_$C -- $R/tools/ubench/fetch_calib > /tmp/fc_$C.log 2>&1; done; tail -3 /tmp/fc_FETCH_SIZE.log; python3 $R/tools/fetch_calib_report.py ) > $O/fetch_calib.txt 2>&1
 python tools/i8_tail.py > $O/i8_tail.txt 2>&1
-python -m pytest tests -m gpu -q 2>&1 | tail -12 > $O/pytest_gpu.txt
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -5 > $O/pytest_gpu.txt
 for S in 32 16 32 16; do echo "== DM_F16X3_SHAPE=$S"; DM_F16X3_SHAPE=$S bash tools/power_trace.sh $O/p_shape.txt python tools/bench_loop.py f16x3 5 2>/dev/null | grep -E "launches|socket power|sclk"; done > $O/power_shapes.txt 2>&1; rm -f $O/p_shape.txt
 ( python tools/e2e_rate.py packed 200 | sed -n 2,2p; python tools/e2e_rate.py raw 200 | sed -n 2,2p; python tools/e2e_rate.py feat 60 | sed -n 2,2p;
   echo "-- the per-read Python path (DEEPMOD_ROWS_IN_C=0) on the same box:";

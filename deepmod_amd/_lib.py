@@ -96,6 +96,8 @@ SIGNATURES = [
     ("dm_map_read", _c.c_int, [_c.c_int, _i64, _c.c_char_p, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     ("dm_signal_event_stats", _c.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_i64), _vp]),
     ("dm_signal_event_stats_batch", _c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("dm_signal_plan_batch", _c.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
+    ("dm_signal_event_stats_device", _c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("dm_events_merge", _i64, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("dm_rows_create", _vp, [_c.c_char]),
     ("dm_rows_destroy", None, [_vp]),
@@ -107,6 +109,7 @@ SIGNATURES = [
     ("dm_rows_emit", _i64, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32)]),
     ("dm_rows_device_info", _c.c_int, [_vp, _c.POINTER(_i64), _c.POINTER(_i64)]),
     ("dm_rows_emit_device", _i64, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32)]),
+    ("dm_rows_emit_resident", _i64, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32)]),
     ("dm_rows_assemble", _c.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64]),
 ]
 

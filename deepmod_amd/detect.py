@@ -699,8 +699,10 @@ def _print_stream_stats(stats, wall, since_start=None):
           % (tot['batches'], tot['slot_batches'], tot['detect_wall'] / len(stats), tot['wait_feed'] / len(stats), tot['merge+bed'] / len(stats))
           + '; device queue: waiting for the device %.1f s, staging copy %.1f s, launches %.1f s'
           % (tot['submit_wait_device'] / len(stats), tot['submit_stage'] / len(stats), tot['submit_launch'] / len(stats))
-          + ('; signal server %.1f s (%.1f s inside dm_signal_event_stats_batch) for %d requests'
-             % (tot['signal_server'] / len(stats), tot['signal_server_call'] / len(stats), tot['signal_requests']) if tot['signal_requests'] else ''))
+          + ('; signal server %.1f s (%.1f s copying requests into page-locked memory, %.1f s inside the signal call) for %d requests; event statistics resident on the device '
+             'for %d of %d rows, the batch loop waited %.2f s for them'
+             % (tot['signal_server'] / len(stats), tot['signal_server_copy'] / len(stats), tot['signal_server_call'] / len(stats), tot['signal_requests'],
+                tot['submit_stats_on_device'], tot['rows'], tot['submit_wait_signal'] / len(stats)) if tot['signal_requests'] else ''))
     if 'at_rank_start' in tot and 'at_drained' in tot:
         n, r0 = len(stats), tot['at_rank_start'] / len(stats)
         print('\ttimeline, seconds after the command began its detect step (mean over ranks): GPU process running %.2f, feeder processes started %.2f, model on the device %.2f, '

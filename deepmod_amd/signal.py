@@ -76,6 +76,26 @@ class SignalNormalizer:
                                                          first_empty.ctypes.data))
         return mean, stdv, first_empty
 
+    def event_stats_device(self, raw, raw_off, ev_start, ev_length, ev_off, block_ptr: int, fb_mean=None, fb_stdv=None):
+        """The RESIDENT form (dm_signal_plan_batch + dm_signal_event_stats_device): the statistics of every merged event of the batch - (mean, stdv,
+        length), the fall-back values fb_mean / fb_stdv merged in for events at or behind a read's first empty event - are written into the device
+        block at block_ptr ([n_events][3] float32) and stay there.  -> (first_empty int64[n], range flag)"""
+        n = len(raw_off) - 1
+        raw = np.ascontiguousarray(raw, dtype=np.int16)
+        st = np.ascontiguousarray(ev_start, dtype=np.uint64)
+        ln = np.ascontiguousarray(ev_length, dtype=np.uint64)
+        raw_off = np.ascontiguousarray(raw_off, np.int64)
+        ev_off = np.ascontiguousarray(ev_off, np.int64)
+        first_empty = np.empty(n, np.int64)
+        _lib.check(self._lib.dm_signal_plan_batch(n, raw_off.ctypes.data, ev_off.ctypes.data, st.ctypes.data, ln.ctypes.data, first_empty.ctypes.data))
+        fm = None if fb_mean is None else np.ascontiguousarray(fb_mean, np.float32)
+        fs = None if fb_stdv is None else np.ascontiguousarray(fb_stdv, np.float32)
+        flags = ctypes.c_int32(0)
+        _lib.check(self._lib.dm_signal_event_stats_device(self._h, n, raw.ctypes.data, raw_off.ctypes.data, st.ctypes.data, ln.ctypes.data, ev_off.ctypes.data,
+                                                          first_empty.ctypes.data, None if fm is None else fm.ctypes.data,
+                                                          None if fs is None else fs.ctypes.data, block_ptr, None, ctypes.byref(flags)))
+        return first_empty, int(flags.value)
+
     def event_stats_batch(self, reads):
         """reads: [(raw int16[n], ev_start uint64[E], ev_length uint64[E])] -> [(mean, stdv, norm dict, first_empty)] with one
         device round trip for the whole list (dm_signal_event_stats_batch; bit-identical to per-read event_stats)."""

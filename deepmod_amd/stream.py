@@ -21,6 +21,7 @@ gloo transport) - only the transport and the device calls are replaced, the shar
 """
 from __future__ import annotations
 
+import ctypes
 import json
 import os
 import queue
@@ -40,7 +41,7 @@ HALF = 10          # windowsize // 2
 class Prepared:
     """One worker batch, ready for the device.  Rows of the reads are concatenated, reads grouped by (contig, strand)."""
     __slots__ = ('_rows', 'pos', 'flags', 'n_rows', 'groups', 'n_windows', 'n_reads', 'errors', 'contig_len', 'timing', 'files', 'on_done', 'f32', 'sel',
-                 'ev3', 'code', 'rdesc')
+                 'ev3', 'code', 'rdesc', 'sig')
 
     @property
     def rows(self):
@@ -48,6 +49,8 @@ class Prepared:
         for them anyway (the CPU backend of the tests, a comparison) gets the host restatement of dm_rows_assemble."""
         if self._rows is None and self.ev3 is not None:
             return assemble_rows(self.ev3, self.code, self.rdesc, self.n_rows)
+        if self._rows is None and self.sig is not None:
+            raise ValueError('the event statistics of this batch stay on the device (resident form): its feature rows exist only there')
         return self._rows
 
     @rows.setter
@@ -60,6 +63,9 @@ class Prepared:
         # show, code u8[n_rows] = one-hot class of a row (255: none), rdesc i64[reads][4] = (first row, row -> event shift, first event, end event);
         # `rows` is then built on the device (HipBackend.submit -> dm_rows_assemble): 13 instead of 28 bytes per row cross the host and PCIe
         self.ev3 = self.code = self.rdesc = None
+        # resident form (round 6): sig = (feeder, request number) of the signal request whose statistics block - (mean, stdv, length) of every merged event
+        # of the batch, written by dm_signal_event_stats_device - stays on the device; code / rdesc as above, rdesc's event indices point into that block
+        self.sig = None
         self.pos = np.zeros(0, np.int64)          # [n_rows classified rows | extra rows]
         self.flags = np.zeros(0, np.uint8)
         self.n_rows = 0
@@ -332,8 +338,24 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                 m_mean, m_stdv = cat(cols['mean'], np.float32), cat(cols['stdv'], np.float32)
                 m_start, m_len, m_base = cat(cols['start'], np.uint64), cat(cols['length'], np.uint64), cat(cols['base'], 'S1')
                 raw_off, mev_off = np.array(raw_offs, np.int64), np.array(ev_offs, np.int64)
+                # resident form (round 6): a batch of raw containers only, whose rows are built on the device anyway - the signal request is POSTED
+                # (samples + event tables into the server's request file, no wait) and its statistics never come back: the feeder needs only
+                # first_empty (host arithmetic, dm_signal_plan_batch) to walk its alignments while the signal kernels run
+                want_resident = (hasattr(normalizer, 'post_arrays') and len(raw_files) == len(files)
+                                 and bool(moptions.get('select_base', os.environ.get('DEEPMOD_SELECT_BASE', '1') != '0'))
+                                 and bool(moptions.get('rows_on_device', os.environ.get('DEEPMOD_ROWS_ON_DEVICE', '1') != '0'))
+                                 and bool(moptions.get('stats_on_device', os.environ.get('DEEPMOD_STATS_ON_DEVICE', '1') != '0')))
                 try:
-                    s_mean, s_stdv, first_empty = normalizer.event_stats_arrays(raw_parts, raw_off, m_start, m_len, mev_off)
+                    if want_resident:
+                        first_empty = np.empty(len(raw_off) - 1, np.int64)
+                        _lib.check(lib.dm_signal_plan_batch(len(raw_off) - 1, raw_off.ctypes.data, mev_off.ctypes.data, m_start.ctypes.data, m_len.ctypes.data,
+                                                            first_empty.ctypes.data))
+                        needs_fb = bool((first_empty < (mev_off[1:] - mev_off[:-1])).any())
+                        out.sig = normalizer.post_arrays(raw_parts, raw_off, m_start, m_len, mev_off, first_empty, m_mean if needs_fb else None,
+                                                         m_stdv if needs_fb else None)
+                        s_mean = s_stdv = None
+                    else:
+                        s_mean, s_stdv, first_empty = normalizer.event_stats_arrays(raw_parts, raw_off, m_start, m_len, mev_off)
                 except _lib.DeepModHipError:
                     # a read the batched signal call cannot take (events covering no signal): the per-read Python path reports it
                     lib.dm_rows_destroy(h)
@@ -396,9 +418,9 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                                  m_len, m_base, s_mean, s_stdv, first_empty, rg_c, rg_lo, rg_hi])
                     _lib.check(lib.dm_rows_add_raw(h, nrec, flag.ctypes.data, pos1.ctypes.data, cig_ptr, seq_ptr, rlen.ctypes.data, cidx.ctypes.data,
                                                    ev_read.ctypes.data, skip.ctypes.data, nct, ref_ptr, ref_len.ctypes.data, len(mev_off) - 1, len(m_mean), mev_off.ctypes.data,
-                                                   m_mean.ctypes.data, m_stdv.ctypes.data, m_len.ctypes.data, m_base.ctypes.data, s_mean.ctypes.data,
-                                                   s_stdv.ctypes.data, first_empty.ctypes.data, len(region), rg_c.ctypes.data, rg_lo.ctypes.data,
-                                                   rg_hi.ctypes.data))
+                                                   m_mean.ctypes.data, m_stdv.ctypes.data, m_len.ctypes.data, m_base.ctypes.data,
+                                                   None if s_mean is None else s_mean.ctypes.data, None if s_stdv is None else s_stdv.ctypes.data,
+                                                   first_empty.ctypes.data, len(region), rg_c.ctypes.data, rg_lo.ctypes.data, rg_hi.ctypes.data))
                     srcs.extend(f5data[q][3] for q, _ in recs)
                     for nm in names:
                         if nm in ref_bytes:
@@ -467,10 +489,13 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
         # device form (round 5): a batch of raw reads only hands over (mean, stdv, length) per event, a class byte per row and a descriptor per
         # read; the [R][7] matrix is built on the device.  moptions['rows_on_device'] = False / DEEPMOD_ROWS_ON_DEVICE=0: rows on the host as before
         dev_form = None
-        if R and compact and bool(moptions.get('rows_on_device', os.environ.get('DEEPMOD_ROWS_ON_DEVICE', '1') != '0')):
+        resident = out.sig is not None
+        if R and compact and (resident or bool(moptions.get('rows_on_device', os.environ.get('DEEPMOD_ROWS_ON_DEVICE', '1') != '0'))):
             ne, nr = ctypes.c_int64(), ctypes.c_int64()
             if lib.dm_rows_device_info(h, ctypes.byref(ne), ctypes.byref(nr)) == 1:
-                dev_form = (int(ne.value), int(nr.value))
+                dev_form = (0 if resident else int(ne.value), int(nr.value))
+        if resident and R and dev_form is None:
+            raise _lib.DeepModHipError('a batch whose statistics stay on the device must be a batch of raw reads')
         if R:
             if dev_form is not None:
                 E, NR = dev_form
@@ -480,6 +505,8 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                 else:
                     out.ev3, out.code, out.rdesc = np.empty((max(E, 1), 3), np.float32), np.empty(R, np.uint8), np.empty((NR, 4), np.int64)
                     out.pos, out.flags, out.sel = np.empty(T, np.int64), np.empty(T, np.uint8), np.empty(S, np.int32)
+                if resident:
+                    out.ev3 = None
                 out.rows = None
             elif alloc is not None:
                 got = alloc(R, T, S) if compact else alloc(R, T)
@@ -496,7 +523,10 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
             in_range = ctypes.c_int32(1)
             sel_dummy = np.zeros(1, np.int32)
             sel_ptr = (out.sel.ctypes.data if S else sel_dummy.ctypes.data) if compact else None
-            if dev_form is not None:
+            if resident:
+                ng = lib.dm_rows_emit_resident(h, rank.ctypes.data, out.code.ctypes.data, out.rdesc.ctypes.data, sel_ptr, out.pos.ctypes.data,
+                                               out.flags.ctypes.data, groups.ctypes.data, len(groups), clen.ctypes.data, len(clen), ctypes.byref(in_range))
+            elif dev_form is not None:
                 ng = lib.dm_rows_emit_device(h, rank.ctypes.data, out.ev3.ctypes.data, out.code.ctypes.data, out.rdesc.ctypes.data, sel_ptr,
                                              out.pos.ctypes.data, out.flags.ctypes.data, groups.ctypes.data, len(groups), clen.ctypes.data, len(clen),
                                              ctypes.byref(in_range))
@@ -671,6 +701,86 @@ def _sig_layout(n: int, n_raw: int, n_ev: int):
     return o
 
 
+def _sig_layout_res(n: int, n_raw: int, n_ev: int, with_fb: bool):
+    """request of the resident form: [raw i16 | raw_off i64 | ev_off i64 | ev_start u64 | ev_length u64 | first_empty i64 | fb_mean f32 | fb_stdv f32]
+    (the last two only when some read of the batch has an empty event) - inputs only: the statistics stay on the device"""
+    up = lambda v: -(-v // 64) * 64
+    o = {}
+    pos = 0
+    for name, nbytes in (('raw', 2 * n_raw), ('raw_off', 8 * (n + 1)), ('ev_off', 8 * (n + 1)), ('ev_start', 8 * n_ev), ('ev_length', 8 * n_ev),
+                         ('first_empty', 8 * n), ('fb_mean', 4 * n_ev if with_fb else 0), ('fb_stdv', 4 * n_ev if with_fb else 0)):
+        o[name] = pos
+        pos = up(pos + nbytes)
+    o['end'] = pos
+    return o
+
+
+class SignalResults:
+    """GPU process: what the signal server threads hand to the batch loop - per resident request (feeder, number) the device block of its
+    statistics, the range flag of dm_signal_event_stats_device and an error text.  The server registers a result when its call has returned (the block
+    is then complete: nothing the batch loop queues afterwards needs a cross-stream wait); the loop takes it when the batch that names it arrives."""
+
+    def __init__(self):
+        self._cv = threading.Condition()
+        self._done = {}
+
+    def put(self, key, block, flags: int = 0, err: Optional[str] = None):
+        with self._cv:
+            self._done[tuple(key)] = (block, flags, err)
+            self._cv.notify_all()
+
+    def take(self, key, timeout: float = 300.0):
+        key = tuple(key)
+        end = time.perf_counter() + timeout
+        with self._cv:
+            while key not in self._done:
+                left = end - time.perf_counter()
+                if left <= 0:
+                    raise RuntimeError('the signal stage never answered request %r' % (key,))
+                self._cv.wait(left)
+            return self._done.pop(key)
+
+    def pending(self):
+        with self._cv:
+            return list(self._done)
+
+
+class DeviceBlockPool:
+    """Grow-only device blocks for the statistics of resident signal requests: taken by a server thread, given back by the batch loop once the launches
+    that read a block have finished (its staging set's marker has passed)."""
+
+    def __init__(self, device: int):
+        self.device = device
+        self._lock = threading.Lock()
+        self._free = []
+        self.allocated = 0
+
+    def take(self, nbytes: int):
+        from . import model as dm
+        with self._lock:
+            best = None
+            for i, b in enumerate(self._free):
+                if b.nbytes >= nbytes and (best is None or b.nbytes < self._free[best].nbytes):
+                    best = i
+            if best is not None:
+                return self._free.pop(best)
+        blk = dm.DeviceArray((int(nbytes * 1.25) + 4096,), np.uint8, self.device)
+        with self._lock:
+            self.allocated += 1
+        return blk
+
+    def give(self, blk):
+        if blk is not None:
+            with self._lock:
+                self._free.append(blk)
+
+    def close(self):
+        with self._lock:
+            blocks, self._free = self._free, []
+        for b in blocks:
+            b.free()
+
+
 class RemoteSignalNormalizer:
     """Feeder-process side of the signal server: the interface of signal.SignalNormalizer that the raw path uses."""
 
@@ -679,6 +789,69 @@ class RemoteSignalNormalizer:
         self.path = os.path.join(shm_dir, 'sig_%d' % wid)
         self.mm = None
         self.size = 0
+        self._posted = 0                   # resident requests posted so far
+        self._acked = set()                # ... whose request file the server has copied (it may be written again)
+        self._res_files = [None, None]     # (mapping, size, path) of the two request files of the resident form
+
+    # ---- resident form: post and go on ----
+    def post_arrays(self, raw_parts, raw_off, ev_start, ev_length, ev_off, first_empty, fb_mean=None, fb_stdv=None):
+        """Write a request of the resident form (dm_signal_event_stats_device) into one of this feeder's two request files and queue it: no wait for the
+        statistics - they stay on the device, the GPU process finds them under the returned (feeder, number) when the batch arrives.  The only wait is
+        for the file itself: request k reuses the file of request k - 2, which the server must have copied into its page-locked memory (its
+        acknowledgement; usually long there)."""
+        import mmap
+        from . import _lib
+        seq = self._posted = self._posted + 1
+        while seq - 2 > 0 and (seq - 2) not in self._acked:
+            self._take_answer(block=True)
+        self._acked.discard(seq - 2)
+        n = len(raw_off) - 1
+        n_raw, n_ev = int(raw_off[-1]), int(ev_off[-1])
+        with_fb = fb_mean is not None and fb_stdv is not None
+        o = _sig_layout_res(n, n_raw, n_ev, with_fb)
+        files = self._res_files
+        slot = seq % 2
+        cur = files[slot]
+        if cur is None or cur[1] < o['end']:
+            if cur is not None:
+                cur[0].close()
+            size = max(1 << 22, int(o['end'] * 1.5))
+            path = self.path + '_r%d' % slot
+            fd = os.open(path, os.O_CREAT | os.O_RDWR, 0o600)
+            try:
+                os.ftruncate(fd, size)
+                cur = files[slot] = (mmap.mmap(fd, size), size, path)
+            finally:
+                os.close(fd)
+        mm, size, path = cur
+        np.concatenate([np.asarray(p) for p in raw_parts], out=np.frombuffer(mm, np.int16, n_raw, o['raw']), casting='same_kind')
+        np.frombuffer(mm, np.int64, n + 1, o['raw_off'])[:] = raw_off
+        np.frombuffer(mm, np.int64, n + 1, o['ev_off'])[:] = ev_off
+        np.frombuffer(mm, np.uint64, n_ev, o['ev_start'])[:] = ev_start
+        np.frombuffer(mm, np.uint64, n_ev, o['ev_length'])[:] = ev_length
+        np.frombuffer(mm, np.int64, n, o['first_empty'])[:] = first_empty
+        if with_fb:
+            np.frombuffer(mm, np.float32, n_ev, o['fb_mean'])[:] = fb_mean
+            np.frombuffer(mm, np.float32, n_ev, o['fb_stdv'])[:] = fb_stdv
+        self.requests.put(('res', self.wid, path, size, n, n_raw, n_ev, seq, with_fb))
+        return (self.wid, seq)
+
+    def _take_answer(self, block: bool = True):
+        """One message from the server: ('ack', number, error) of a resident request, or the answer (None / error text) of a synchronous one."""
+        from . import _lib
+        msg = self.answers.get() if block else self.answers.get_nowait()
+        if isinstance(msg, tuple) and msg and msg[0] == 'ack':
+            if msg[2] is not None:
+                raise _lib.DeepModHipError(msg[2])
+            self._acked.add(msg[1])
+            return 'ack'
+        return ('answer', msg)
+
+    def _wait_answer(self):
+        while True:
+            got = self._take_answer(block=True)
+            if got != 'ack':
+                return got[1]
 
     def _ensure(self, nbytes: int):
         import mmap
@@ -711,7 +884,7 @@ class RemoteSignalNormalizer:
         np.concatenate([np.asarray(r[1]) for r in reads], out=np.frombuffer(mm, np.uint64, n_ev, o['ev_start']), casting='same_kind')
         np.concatenate([np.asarray(r[2]) for r in reads], out=np.frombuffer(mm, np.uint64, n_ev, o['ev_length']), casting='same_kind')
         self.requests.put((self.wid, self.path, self.size, n, n_raw, n_ev))
-        err = self.answers.get()
+        err = self._wait_answer()
         if err is not None:
             raise _lib.DeepModHipError(err)
         mean = np.frombuffer(mm, np.float32, n_ev, o['mean']).copy()
@@ -736,7 +909,7 @@ class RemoteSignalNormalizer:
         np.frombuffer(mm, np.uint64, n_ev, o['ev_start'])[:] = ev_start
         np.frombuffer(mm, np.uint64, n_ev, o['ev_length'])[:] = ev_length
         self.requests.put((self.wid, self.path, self.size, n, n_raw, n_ev))
-        err = self.answers.get()
+        err = self._wait_answer()
         if err is not None:
             raise _lib.DeepModHipError(err)
         return (np.frombuffer(mm, np.float32, n_ev, o['mean']).copy(), np.frombuffer(mm, np.float32, n_ev, o['stdv']).copy(),
@@ -752,12 +925,20 @@ class RemoteSignalNormalizer:
         if self.mm is not None:
             self.mm.close()
             self.mm = None
+        for cur in self._res_files:
+            if cur is not None:
+                cur[0].close()
+        self._res_files = [None, None]
 
 
-def signal_server(requests, answers, device: int, stats=None):
-    """Thread body in the GPU process: requests (wid, path, file size, n, n_raw, n_ev) until None; answers[wid] gets None or an
-    error text.  Inputs are copied to page-locked memory (uploads from the shared-memory mapping itself are slow), the C ABI
-    writes its results there, and they go back into the request file."""
+def signal_server(requests, answers, device: int, stats=None, results: Optional[SignalResults] = None, blocks: Optional[DeviceBlockPool] = None):
+    """Thread body in the GPU process: requests until None.
+      (wid, path, file size, n, n_raw, n_ev)                          synchronous form: answers[wid] gets None or an error text; the statistics
+                                                                       go back into the request file;
+      ('res', wid, path, file size, n, n_raw, n_ev, number, with_fb)  resident form (round 6): answers[wid] gets ('ack', number, error) as soon
+                                                                       as the request file has been copied (the feeder may write it again), the
+                                                                       statistics go into a device block registered in `results` under (wid, number).
+    Inputs are copied to page-locked memory (uploads from the shared-memory mapping itself are slow)."""
     import mmap
     from . import _lib, model as dm, signal as dmsignal
     norm = None           # its dm_signal handle is made for the first request: a run of feature containers never needs one, and
@@ -769,40 +950,68 @@ def signal_server(requests, answers, device: int, stats=None):
             req = requests.get()
             if req is None:
                 return
-            wid, path, size, n, n_raw, n_ev = req
+            resident = req[0] == 'res'
+            if resident:
+                _, wid, path, size, n, n_raw, n_ev, seq, with_fb = req
+            else:
+                wid, path, size, n, n_raw, n_ev = req
             t0 = time.perf_counter()
+            acked = False
             try:
                 if norm is None:
                     norm = dmsignal.SignalNormalizer(device)
-                if maps.get(wid, (None, 0))[1] != size:
-                    if wid in maps:
-                        maps[wid][0].close()
+                if maps.get(path, (None, 0))[1] != size:
+                    if path in maps:
+                        maps[path][0].close()
                     fd = os.open(path, os.O_RDWR)
                     try:
-                        maps[wid] = (mmap.mmap(fd, size), size)
+                        maps[path] = (mmap.mmap(fd, size), size)
                     finally:
                         os.close(fd)
-                mm = maps[wid][0]
-                o = _sig_layout(n, n_raw, n_ev)
+                mm = maps[path][0]
+                o = _sig_layout_res(n, n_raw, n_ev, with_fb) if resident else _sig_layout(n, n_raw, n_ev)
+                n_in = o['end'] if resident else o['in_end']
                 if pinned is None or pinned.nbytes < o['end']:
                     if pinned is not None:
                         pinned.free()
                     pinned = dm.PinnedArray(int(o['end'] * 1.5) + 4096, device)
                 pv = pinned.view(np.uint8, o['end'])
-                pv[:o['in_end']] = np.frombuffer(mm, np.uint8, o['in_end'])
+                pv[:n_in] = np.frombuffer(mm, np.uint8, n_in)
                 base = pinned.ptr
                 t1 = time.perf_counter()
-                rc = lib.dm_signal_event_stats_batch(norm._h, n, base + o['raw'], base + o['raw_off'], base + o['ev_start'], base + o['ev_length'],
-                                                     base + o['ev_off'], base + o['mean'], base + o['stdv'], base + o['norm6'], base + o['first_empty'])
-                if stats is not None:
-                    stats['signal_server_call'] += time.perf_counter() - t1
-                if rc != 0:
-                    answers[wid].put(_lib.last_error())
-                    continue
-                np.frombuffer(mm, np.uint8, o['end'] - o['in_end'], o['in_end'])[:] = pv[o['in_end']:]
-                answers[wid].put(None)
-            except Exception as exc:                        # the feeder turns it into a per-read failure
-                answers[wid].put('signal server: %r' % (exc,))
+                if resident:
+                    answers[wid].put(('ack', seq, None))          # the request file is free again
+                    acked = True
+                    blk = blocks.take(12 * max(n_ev, 1))
+                    flags = ctypes.c_int32(0)
+                    rc = lib.dm_signal_event_stats_device(norm._h, n, base + o['raw'], base + o['raw_off'], base + o['ev_start'], base + o['ev_length'],
+                                                          base + o['ev_off'], base + o['first_empty'], (base + o['fb_mean']) if with_fb else None,
+                                                          (base + o['fb_stdv']) if with_fb else None, blk.ptr, None, ctypes.byref(flags))
+                    if stats is not None:
+                        stats['signal_server_call'] += time.perf_counter() - t1
+                        stats['signal_server_copy'] += t1 - t0
+                    if rc != 0:
+                        blocks.give(blk)
+                        results.put((wid, seq), None, 0, 'signal stage: ' + _lib.last_error())
+                    else:
+                        results.put((wid, seq), blk, int(flags.value), None)
+                else:
+                    rc = lib.dm_signal_event_stats_batch(norm._h, n, base + o['raw'], base + o['raw_off'], base + o['ev_start'], base + o['ev_length'],
+                                                         base + o['ev_off'], base + o['mean'], base + o['stdv'], base + o['norm6'], base + o['first_empty'])
+                    if stats is not None:
+                        stats['signal_server_call'] += time.perf_counter() - t1
+                    if rc != 0:
+                        answers[wid].put(_lib.last_error())
+                        continue
+                    np.frombuffer(mm, np.uint8, o['end'] - o['in_end'], o['in_end'])[:] = pv[o['in_end']:]
+                    answers[wid].put(None)
+            except Exception as exc:                        # the feeder turns it into a per-read failure / the batch loop fails the run
+                if resident:
+                    if not acked:
+                        answers[wid].put(('ack', seq, None))
+                    results.put((wid, seq), None, 0, 'signal server: %r' % (exc,))
+                else:
+                    answers[wid].put('signal server: %r' % (exc,))
             if stats is not None:
                 stats['signal_server'] += time.perf_counter() - t0
                 stats['signal_requests'] += 1
@@ -877,7 +1086,8 @@ def feeder_process_main(moptions, work, ready, device: int, shm_dir: str, wid: i
             meta = {'path': path if 'mm' in holder else None, 'slot': holder.get('slot'), 'n_rows': pb.n_rows, 'n_pos': len(pb.pos),
                     'groups': pb.groups, 'n_windows': pb.n_windows, 'n_reads': pb.n_reads, 'errors': {k: list(v) for k, v in pb.errors.items()},
                     'contig_len': dict(pb.contig_len), 'timing': dict(pb.timing), 'files': list(pb.files), 'f32': pb.f32,
-                    'n_sel': None if pb.sel is None else len(pb.sel), 'dev': holder.get('dev') if pb.ev3 is not None else None}
+                    'n_sel': None if pb.sel is None else len(pb.sel), 'dev': holder.get('dev') if (pb.ev3 is not None or pb.code is not None) else None,
+                    'sig': pb.sig}
             pb.rows = pb.pos = pb.flags = pb.sel = pb.ev3 = pb.code = pb.rdesc = None          # drop the views before a mapping goes away
             if 'mm' in holder:
                 holder['mm'].close()
@@ -916,8 +1126,11 @@ def prepared_from_shm(meta, slot_buffer=None) -> Prepared:
             os.close(fd)
             os.unlink(meta['path'])
         views = mk(mm)
+    pb.sig = tuple(meta['sig']) if meta.get('sig') is not None else None
     if views is not None and dev is not None:
         pb.ev3, pb.code, pb.rdesc, pb.pos, pb.flags = views[:5]
+        if pb.sig is not None:             # resident form: the statistics are a device block of the signal stage, nothing per event in the slot
+            pb.ev3 = None
         pb.rows = None
         pb.sel = views[5] if n_sel else np.zeros(0, np.int32)
         return pb
@@ -954,7 +1167,10 @@ class HipBackend:
         # 4.5 % slower and the end-to-end rate no better (profiles/r02/README.md): default 0
         self.model.set_option(_lib.DM_OPT_RESERVED_CUS, int(moptions.get('reserved_cus', os.environ.get('DEEPMOD_RESERVED_CUS', 0))))
         self._dm = dm
-        self._sets = [{'host': None, 'dev': None} for _ in range(self.NSET)]
+        self._sets = [{'host': None, 'dev': None, 'sig_block': None} for _ in range(self.NSET)]
+        # resident form: set by the engine when signal server threads run in this process (stream.SignalResults / DeviceBlockPool)
+        self.signal_results = None
+        self.signal_blocks = None
         self._k = 0
         self._h2d = self._lib.dm_model_h2d_ahead if int(os.environ.get('DEEPMOD_COPY_AHEAD', 1)) else self._lib.dm_model_h2d_async
         self.timing = defaultdict(float)   # where submit() spends the GPU process' time
@@ -979,16 +1195,30 @@ class HipBackend:
     def submit(self, pb: Prepared, summaries) -> None:
         """Queue one batch: stage, upload, classify every row (windows assembled on the device), accumulate per group.
         Returns after enqueue; the batch's own arrays are free again on return (pb.on_done is called)."""
+        resident = pb.sig is not None              # the statistics of the batch's events are a device block of the signal stage
+        sig_block = None
+        if resident:
+            if self.signal_results is None:
+                raise RuntimeError('a batch in the resident form reached a backend without a signal stage')
+            t0 = time.perf_counter()
+            sig_block, sig_flags, sig_err = self.signal_results.take(pb.sig)
+            self.timing['wait_signal'] += time.perf_counter() - t0
+            if sig_err is not None:
+                raise self._lib_mod.DeepModHipError(sig_err)
+            if sig_flags & 1:
+                pb.f32 = True
         if pb.n_rows == 0:
+            if sig_block is not None:
+                self.signal_blocks.give(sig_block)
             if pb.on_done is not None:
                 pb.on_done()
                 pb.on_done = None
             return
         R, T = pb.n_rows, len(pb.pos)
         S = 0 if pb.sel is None else len(pb.sel)
-        dev_form = pb.ev3 is not None              # raw reads in the device form: the feature rows are built on the device (dm_rows_assemble)
+        dev_form = pb.ev3 is not None or resident  # raw reads in the device form: the feature rows are built on the device (dm_rows_assemble)
         if dev_form:
-            E, NR = len(pb.ev3), len(pb.rdesc)
+            E, NR = (0 if resident else len(pb.ev3)), len(pb.rdesc)
             o = _shm_layout_dev(R, T, S, E, NR)
             o_pos, o_flags, end, o_sel = o['pos'], o['flags'], o['end'], o['sel']
             o_rows = -(-end // _ALIGN) * _ALIGN      # device only: nothing is uploaded behind `end`
@@ -1002,10 +1232,14 @@ class HipBackend:
         i = self._k % self.NSET
         self._k += 1
         self.model.wait_mark(i)                    # the launches that read this set (batch k - NSET) are done
+        if self._sets[i]['sig_block'] is not None: # ... and with them the statistics block that batch read
+            self.signal_blocks.give(self._sets[i]['sig_block'])
+        self._sets[i]['sig_block'] = sig_block
         t1 = time.perf_counter()
         host, dev = self._staging(self._sets[i], o_cls + n_cls)
         if dev_form:
-            np.copyto(host.view(np.float32, 3 * E, o['ev3']).reshape(E, 3), pb.ev3, casting='same_kind')
+            if not resident:
+                np.copyto(host.view(np.float32, 3 * E, o['ev3']).reshape(E, 3), pb.ev3, casting='same_kind')
             np.copyto(host.view(np.uint8, R, o['code']), pb.code, casting='same_kind')
             np.copyto(host.view(np.int64, 4 * NR, o['rdesc']).reshape(NR, 4), pb.rdesc, casting='same_kind')
         else:
@@ -1023,8 +1257,10 @@ class HipBackend:
         self._lib_check(self._h2d(self.model._h, dev.ptr, host.ptr, end))
         d_rows, d_pos, d_flags, d_cls, d_sel = dev.ptr + o_rows, dev.ptr + o_pos, dev.ptr + o_flags, dev.ptr + o_cls, dev.ptr + o_sel
         if dev_form:
-            self.model.assemble_rows_device(d_rows, dev.ptr + o['code'], dev.ptr + o['ev3'], dev.ptr + o['rdesc'], NR, R)
+            self.model.assemble_rows_device(d_rows, dev.ptr + o['code'], sig_block.ptr if resident else dev.ptr + o['ev3'], dev.ptr + o['rdesc'], NR, R)
             self.timing['rows_on_device'] += R
+            if resident:
+                self.timing['stats_on_device'] += R
         if pb.sel is None:
             # classic form: window centred on row r -> cls[r]; rows 0..9 and R-10..R-1 are padding of the first / last read
             classify = lambda: self.model.predict_rows_device(d_rows, R, HALF, R - 2 * HALF, d_cls + HALF)
@@ -1068,7 +1304,11 @@ class HipBackend:
             for blk in (st['host'], st['dev']):
                 if blk is not None:
                     blk.free()
-            st['host'] = st['dev'] = None
+            if st['sig_block'] is not None and self.signal_blocks is not None:
+                self.signal_blocks.give(st['sig_block'])
+            st['host'] = st['dev'] = st['sig_block'] = None
+        if self.signal_blocks is not None:
+            self.signal_blocks.close()
         self.sess.close()
 
 
@@ -1213,7 +1453,8 @@ class StreamEngine:
         if self.mo.get('signal_server', True) and (make_backend is not None or hasattr(self.backend, 'device')):
             sig_requests = ctx.Queue()
             sig_answers = [ctx.Queue() for _ in range(n_procs)]
-            server = [threading.Thread(target=signal_server, args=(sig_requests, sig_answers, device, self.stats), daemon=True)
+            sig_results, sig_blocks = SignalResults(), DeviceBlockPool(device)
+            server = [threading.Thread(target=signal_server, args=(sig_requests, sig_answers, device, self.stats, sig_results, sig_blocks), daemon=True)
                       for _ in range(max(1, int(self.mo.get('signal_servers', os.environ.get('DEEPMOD_SIGNAL_SERVERS', 2)))))]     # each with its own dm_signal handle / stream
             for th in server:
                 th.start()
@@ -1229,6 +1470,8 @@ class StreamEngine:
                 t0 = time.perf_counter()
                 self.backend = make_backend()
                 self.stats['backend_init'] += time.perf_counter() - t0
+            if server is not None and hasattr(self.backend, 'signal_results'):
+                self.backend.signal_results, self.backend.signal_blocks = sig_results, sig_blocks
             self.stats['at_backend_ready'] = time.perf_counter() - t_start
             done = 0
             while done < n_procs:

@@ -319,6 +319,20 @@ int dm_signal_event_stats_batch(dm_signal* s, int64_t n_reads, const int16_t* ra
                                 const uint64_t* ev_length, const int64_t* ev_off, float* ev_mean, float* ev_stdv, double* norm6,
                                 int64_t* first_empty);
 
+/* The RESIDENT form (round 6; SURVEY 8f1 + 8f3: "fuse get_Feature's output rows straight into the kernel"): the per-event statistics never leave the
+ * device.  dm_signal_plan_batch (host only, no device call) makes the checks of the batched call and returns first_empty [n_reads] - all a feeder needs
+ * from the signal stage before it walks its alignments (myDetect.py:334-340 cuts the event table there).  dm_signal_event_stats_device runs the same
+ * four kernels and writes d_ev3 [n_events][3] = (mean, stdv, length) of every merged event of the batch into a device block of the caller - the three
+ * values get_Feature (:892-900) copies into a feature row - with the basecaller's values (fb_mean / fb_stdv, host, may be NULL when no read has an empty
+ * event) merged in for events at or behind first_empty.  dm_rows_emit_resident's descriptors index that block and dm_rows_assemble reads it in place: no
+ * D2H -> feeder -> H2D of the statistics.  The block is complete when the call returns; host arrays should be page-locked (dm_host_alloc).
+ * flags (optional): bit 0 = a value outside the split-f16 kernels' range (the batch then takes DM_PREC_F32). */
+int dm_signal_plan_batch(int64_t n_reads, const int64_t* raw_off, const int64_t* ev_off, const uint64_t* ev_start, const uint64_t* ev_length,
+                         int64_t* first_empty);
+int dm_signal_event_stats_device(dm_signal* s, int64_t n_reads, const int16_t* raw, const int64_t* raw_off, const uint64_t* ev_start,
+                                 const uint64_t* ev_length, const int64_t* ev_off, const int64_t* first_empty, const float* fb_mean, const float* fb_stdv,
+                                 float* d_ev3, double* norm6, int32_t* flags);
+
 /* ---- SAM record -> per-base alignment table (host code, no GPU needed) ---------------------
  * Replaces the alignment walk of handle_record, myDetect.py:515-714: clip stripping, one row per M/I/D/N/=/X
  * position, first/last-match trimming of table and event slice, '-' strand flip + complement, the CpG gap swap.
@@ -407,6 +421,11 @@ int64_t dm_rows_emit(dm_rowsbatch* h, const int32_t* contig_rank, float* rows, i
 int dm_rows_device_info(dm_rowsbatch* h, int64_t* n_events, int64_t* n_reads);
 int64_t dm_rows_emit_device(dm_rowsbatch* h, const int32_t* contig_rank, float* ev3, uint8_t* code, int64_t* rdesc, int32_t* sel_row, int64_t* pos,
                             uint8_t* flags, int64_t* groups, int64_t cap_groups, int64_t* contig_len, int64_t n_contig_len, int32_t* in_range);
+/* The RESIDENT form (round 6): reads added by dm_rows_add_raw with s_mean == s_stdv == NULL and first_empty given (dm_signal_plan_batch) - their
+ * statistics are the device block of dm_signal_event_stats_device.  No ev3: rdesc's event indices are positions in the batch's merged event tables
+ * (= rows of that block); in_range covers the event lengths and the fall-back values, the signal stage reports the range of its own values. */
+int64_t dm_rows_emit_resident(dm_rowsbatch* h, const int32_t* contig_rank, uint8_t* code, int64_t* rdesc, int32_t* sel_row, int64_t* pos, uint8_t* flags,
+                              int64_t* groups, int64_t cap_groups, int64_t* contig_len, int64_t n_contig_len, int32_t* in_range);
 int dm_rows_assemble(dm_model* m, float* d_rows, const uint8_t* d_code, const float* d_ev3, const int64_t* d_rdesc, int64_t n_reads, int64_t n_rows);
 
 #ifdef __cplusplus

@@ -170,6 +170,73 @@ def test_batched_call_is_bit_identical_to_per_read_calls():
 
 
 @pytest.mark.gpu
+def test_resident_statistics_block_equals_the_batched_call():
+    """Round 6 (dm_signal_plan_batch + dm_signal_event_stats_device): the statistics that stay on the device are, bit for bit, what the batched call
+    returns to the host with the reference's rule applied (events before a read's first empty event take the signal's statistics, the ones behind keep
+    the basecaller's, myDetect.py:334-340), next to float(length) - the three values get_Feature copies into a feature row (:892-900).  first_empty
+    from the host-only planner equals the batched call's; a read with an empty event and no fall-back values is refused; a length beyond the
+    split-f16 kernels' range raises the range flag; a read that makes the device order statistics step aside (constant signal) takes the same path
+    as in the batched call."""
+    from deepmod_amd import _lib, signal
+    from deepmod_amd.model import DeviceArray
+    cases = [_random_case(60 + i, n, ml) for i, (n, ml) in enumerate([(120_000, 9.0), (65_536, 2.0), (90_001, 11.0), (300_000, 300.0), (7_000, 5.0)])]
+    raw, start, length = cases[2]
+    start, length = start.copy(), length.copy()
+    start[700] = np.uint64(len(raw) + 5)                                 # an empty slice in the middle (> 500: the reference cuts the table there)
+    cases[2] = (raw, start, length)
+    raw, start, length = cases[4]
+    start, length = start.copy(), length.copy()
+    start[40] = np.uint64(len(raw))                                      # ... and one at index 40 (<= 500: the table keeps its length)
+    cases[4] = (raw, start, length)
+    nz = signal.SignalNormalizer(0)
+    batch = nz.event_stats_batch(cases)
+    raw_off = np.concatenate([[0], np.cumsum([len(c[0]) for c in cases])]).astype(np.int64)
+    ev_off = np.concatenate([[0], np.cumsum([len(c[1]) for c in cases])]).astype(np.int64)
+    raw_all = np.concatenate([c[0] for c in cases])
+    st, ln = np.concatenate([c[1] for c in cases]), np.concatenate([c[2] for c in cases])
+    n_ev = int(ev_off[-1])
+    rng = np.random.default_rng(5)
+    fb_mean, fb_stdv = rng.normal(0, 1, n_ev).astype(np.float32), rng.random(n_ev).astype(np.float32)
+    blk = DeviceArray((n_ev, 3), np.float32, 0)
+    try:
+        nz.event_stats_device(raw_all, raw_off, st, ln, ev_off, blk.ptr)
+        raise AssertionError('a read with an empty event needs fall-back values')
+    except _lib.DeepModHipError as exc:
+        assert 'fall-back' in str(exc)
+    fe, flag = nz.event_stats_device(raw_all, raw_off, st, ln, ev_off, blk.ptr, fb_mean, fb_stdv)
+    got = blk.to_host()
+    assert flag == 0
+    assert fe.tolist() == [b[3] for b in batch] and fe[2] == 700 and fe[4] == 40
+    for r, (mean, stdv, _, f) in enumerate(batch):
+        e0, e1 = int(ev_off[r]), int(ev_off[r + 1])
+        want_mean, want_stdv = fb_mean[e0:e1].copy(), fb_stdv[e0:e1].copy()
+        want_mean[:f], want_stdv[:f] = mean[:f], stdv[:f]
+        assert _same_f32(got[e0:e1, 0], want_mean) and _same_f32(got[e0:e1, 1], want_stdv)
+        assert _same_f32(got[e0:e1, 2], ln[e0:e1].astype(np.float64).astype(np.float32))
+    # a stalled event of 70,000 samples: representable by the fp32 kernel only
+    ln2 = ln.copy()
+    ln2[10] = 70_000
+    _, flag = nz.event_stats_device(raw_all, raw_off, st, ln2, ev_off, blk.ptr, fb_mean, fb_stdv)
+    assert flag == 1
+    # the host order statistics (constant signal: division by zero like numpy) behind the same call
+    const = np.full(30_000, 612, np.int16)
+    cl = np.full(3000, 10, np.uint64)
+    cs = (np.arange(3000) * 10).astype(np.uint64)
+    with np.errstate(all='ignore'):
+        ref = nz.event_stats_batch([cases[0], (const, cs, cl)])
+        ro2 = np.array([0, len(cases[0][0]), len(cases[0][0]) + len(const)], np.int64)
+        eo2 = np.array([0, len(cases[0][1]), len(cases[0][1]) + len(cs)], np.int64)
+        blk2 = DeviceArray((int(eo2[-1]), 3), np.float32, 0)
+        _, flag = nz.event_stats_device(np.concatenate([cases[0][0], const]), ro2, np.concatenate([cases[0][1], cs]), np.concatenate([cases[0][2], cl]), eo2, blk2.ptr)
+        got2 = blk2.to_host()
+    assert flag == 1                                                       # NaN statistics: the fp32 kernel reproduces what the reference would feed its graph
+    assert _same_f32(got2[:eo2[1], 0], ref[0][0]) and _same_f32(got2[eo2[1]:, 0], ref[1][0]) and _same_f32(got2[eo2[1]:, 1], ref[1][1])
+    blk.free()
+    blk2.free()
+    nz.close()
+
+
+@pytest.mark.gpu
 def test_device_order_statistics_equal_host_order_statistics(monkeypatch):
     """The batched call computes the four medians of every read on the device (signal_norm_batch_kernel); with
     DEEPMOD_SIGNAL_HOST_NORM=1 it takes the host path (norm_from_hist).  Every median, limit, mean and stdv must agree bit for

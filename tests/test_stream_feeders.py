@@ -288,6 +288,91 @@ def test_compiled_batch_equals_python_batch_on_raw_containers(tmp_path, monkeypa
         assert (g2.n_reads > 0) == expect_some and g2.n_reads < got.n_reads
 
 
+class _PostingOracleNormalizer(_OracleNormalizer):
+    """TEST stand-in for the resident form of the signal stage: post_arrays() records the request and builds, from the signal oracle, the block
+    dm_signal_event_stats_device would leave on the device - ev3 [n_events][3] = (mean, stdv, length) of every merged event of the batch, the
+    fall-back values merged in for events at or behind a read's first empty event."""
+
+    def __init__(self):
+        self.blocks = {}
+
+    def post_arrays(self, raw_parts, raw_off, ev_start, ev_length, ev_off, first_empty, fb_mean=None, fb_stdv=None):
+        mean, stdv, fe = self.event_stats_arrays(raw_parts, raw_off, ev_start, ev_length, ev_off)
+        assert np.array_equal(fe, first_empty), 'dm_signal_plan_batch and the signal stage disagree on the first empty event'
+        ev3 = np.empty((len(ev_start), 3), np.float32)
+        ev3[:, 0], ev3[:, 1], ev3[:, 2] = mean, stdv, ev_length.astype(np.float64).astype(np.float32)
+        for r in range(len(raw_off) - 1):
+            lo = ev_off[r] + min(int(first_empty[r]), int(ev_off[r + 1] - ev_off[r]))
+            if lo < ev_off[r + 1]:
+                assert fb_mean is not None, 'a read with an empty event and no fall-back values'
+                ev3[lo:ev_off[r + 1], 0], ev3[lo:ev_off[r + 1], 1] = fb_mean[lo:ev_off[r + 1]], fb_stdv[lo:ev_off[r + 1]]
+        key = (0, len(self.blocks) + 1)
+        self.blocks[key] = ev3
+        return key
+
+
+def test_resident_form_of_a_raw_batch_equals_the_device_form(tmp_path):
+    """Round 6: with a signal stage that keeps its statistics on the device (post_arrays), a batch of raw containers hands over NO per-event values -
+    only a class byte per row, a descriptor per read whose event indices point into the signal stage's block, the window list, positions and flags.
+    Assembled from that block (stream.assemble_rows = the host restatement of dm_rows_assemble) the feature rows are those of the device form, and
+    everything else of the batch is identical.  One read gets an empty event (its table is cut there, the fall-back values take over)."""
+    from deepmod_amd import npzmap
+    files, fasta = synth_reads.write_synthetic_raw_run(str(tmp_path / 'in'), n_reads=14, reads_per_file=5, genome_len=30000, seed=6,
+                                                       chrom='chrS', min_len=300, max_len=1200)
+    # an event that starts behind the end of the signal: an EMPTY slice at index 60 of the second read of the first container (<= 500: the table keeps its length,
+    # events from there on keep the basecaller's values, myDetect.py:334-340)
+    z = {k: np.array(v) for k, v in npzmap.load(files[0]).items()}          # copies: the file is rewritten below, its mapping must not be read again
+    eo = z['ev_off']
+    st = np.array(z['ev_start'])
+    st[eo[1] + 60] = int(z['raw_off'][2] - z['raw_off'][1]) + 1000
+    z['ev_start'] = st
+    npzmap.savez_aligned(files[0], **z)
+    mo = {'Base': 'C', 'outFolder': str(tmp_path), 'fnum': 7, 'hidden': 100, 'windowsize': 21, 'Ref': fasta, 'alignStr': 'minimap2',
+          'region': [[None, None, None]], 'ConUnk': True, 'SignalGroup': 'simple', 'outLevel': 3, 'select_base': True}
+    plain = _OracleNormalizer()
+    dev = stream._prepare_batch_c(dict(mo), files, lambda: plain)
+    assert dev.ev3 is not None and dev.sig is None
+    posting = _PostingOracleNormalizer()
+    res = stream._prepare_batch_c(dict(mo), files, lambda: posting)
+    assert res.sig == (0, 1) and res.ev3 is None and res._rows is None and res.code is not None
+    block = posting.blocks[res.sig]
+    assert np.array_equal(res.code, dev.code) and np.array_equal(res.sel, dev.sel) and np.array_equal(res.pos, dev.pos) and np.array_equal(res.flags, dev.flags)
+    assert res.groups == dev.groups and res.n_rows == dev.n_rows and res.n_reads == dev.n_reads and res.f32 == dev.f32 and res.contig_len == dev.contig_len
+    assert np.array_equal(res.rdesc[:, 0], dev.rdesc[:, 0]) and (res.rdesc[:, 3] - res.rdesc[:, 2] == dev.rdesc[:, 3] - dev.rdesc[:, 2]).all()
+    rows = stream.assemble_rows(block, res.code, res.rdesc, res.n_rows)
+    assert np.array_equal(rows, dev.rows, equal_nan=True) and rows[:, 4:].any()
+    # the block holds every merged event of the batch in the order of the request, the batch's own ev3 the ones its rows cover in the order of its groups
+    assert len(block) >= len(dev.ev3) and res.rdesc[:, 3].max() <= len(block) and not np.array_equal(block[:len(dev.ev3)], dev.ev3)
+    # stats_on_device = False: the same normalizer is asked for host arrays and the batch comes in the device form
+    host = stream._prepare_batch_c(dict(mo, stats_on_device=False), files, lambda: posting)
+    assert host.sig is None and np.array_equal(host.ev3, dev.ev3, equal_nan=True)
+    # through a feeder process' hand-over: nothing per event in the slot
+    work, ready = queue.Queue(), queue.Queue()
+    work.put((files, 0, 0))
+    shm = str(tmp_path / 'shm_res')
+    os.makedirs(shm)
+    from deepmod_amd import signal as dmsignal
+    import pytest
+    mp = pytest.MonkeyPatch()
+    try:
+        mp.setattr(dmsignal, 'SignalNormalizer', lambda device: posting)
+        stream.feeder_process_main(dict(mo), work, ready, 0, shm, 0)
+    finally:
+        mp.undo()
+    meta = ready.get()
+    assert meta is not None and 'failed' not in meta, meta
+    assert tuple(meta["sig"]) == (0, 2) and meta["dev"] == (0, res.n_reads)
+    via = stream.prepared_from_shm(meta)
+    assert via.sig == (0, 2) and via.ev3 is None and np.array_equal(via.code, res.code) and np.array_equal(via.rdesc, res.rdesc)
+    assert np.array_equal(via.sel, res.sel) and np.array_equal(via.pos, res.pos) and via.groups == res.groups
+    try:
+        via.rows
+        raise AssertionError('a resident batch has no feature rows on the host')
+    except ValueError:
+        pass
+    assert ready.get() is None
+
+
 def test_compact_batch_without_any_base_of_interest(tmp_path):
     """A batch whose reads hold no base of interest at all (an all-T genome, --Base C): feature rows but no window to classify, no
     positions, no extras - through the compiled path, the shared-memory hand-over and the engine (no BED file is written)."""

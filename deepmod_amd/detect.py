@@ -703,6 +703,8 @@ def _print_stream_stats(stats, wall, since_start=None):
              'for %d of %d rows, the batch loop waited %.2f s for them'
              % (tot['signal_server'] / len(stats), tot['signal_server_copy'] / len(stats), tot['signal_server_call'] / len(stats), tot['signal_requests'],
                 tot['submit_stats_on_device'], tot['rows'], tot['submit_wait_signal'] / len(stats)) if tot['signal_requests'] else ''))
+    if tot['signal_requests']:
+        print('\tsignal stage: %d samples, %d merged events in %d requests' % (tot['signal_samples'], tot['signal_events'], tot['signal_requests']))
     if 'at_rank_start' in tot and 'at_drained' in tot:
         n, r0 = len(stats), tot['at_rank_start'] / len(stats)
         print('\ttimeline, seconds after the command began its detect step (mean over ranks): GPU process running %.2f, feeder processes started %.2f, model on the device %.2f, '

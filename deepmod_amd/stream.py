@@ -1015,6 +1015,8 @@ def signal_server(requests, answers, device: int, stats=None, results: Optional[
             if stats is not None:
                 stats['signal_server'] += time.perf_counter() - t0
                 stats['signal_requests'] += 1
+                stats['signal_samples'] += n_raw
+                stats['signal_events'] += n_ev
     finally:
         for mm, _ in maps.values():
             mm.close()

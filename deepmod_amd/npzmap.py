@@ -83,20 +83,58 @@ def savez_aligned(file, **arrays) -> None:
             fh.close()
 
 
+def _central_directory(mm):
+    """[(member name, compression method, offset of the local header)] read straight from the mapping (end-of-central-directory record, then the
+    fixed 46-byte entries), or None for anything this does not cover (zip64 sizes, an archive comment that hides the record, a damaged file) -
+    the caller then asks zipfile.  zipfile's own parser costs 0.2 ms per container in Python objects; a feeder opens a thousand of them."""
+    n = len(mm)
+    if n < 22:
+        return None
+    tail = max(0, n - 22 - 1024)
+    at = mm.rfind(b'PK\x05\x06', tail)
+    if at < 0 or at + 22 > n:
+        return None
+    n_disk, n_total, cd_size, cd_off = struct.unpack('<HHII', mm[at + 8:at + 20])
+    if n_disk != n_total or n_total == 0xFFFF or cd_off == 0xFFFFFFFF or cd_off + cd_size > at:
+        return None
+    out, pos = [], cd_off
+    for _ in range(n_total):
+        if pos + 46 > n or mm[pos:pos + 4] != b'PK\x01\x02':
+            return None
+        method, = struct.unpack('<H', mm[pos + 10:pos + 12])
+        csize, usize, n_name, n_extra, n_comment = struct.unpack('<IIHHH', mm[pos + 20:pos + 34])
+        ho, = struct.unpack('<I', mm[pos + 42:pos + 46])
+        if csize == 0xFFFFFFFF or usize == 0xFFFFFFFF or ho == 0xFFFFFFFF:
+            return None
+        try:
+            name = mm[pos + 46:pos + 46 + n_name].decode('utf-8')
+        except UnicodeDecodeError:
+            return None
+        out.append((name, method, ho))
+        pos += 46 + n_name + n_extra + n_comment
+    return out
+
+
 def load(path: str) -> Dict[str, np.ndarray]:
     """name -> array for every member of an .npz file; views into one read-only mapping where the member is stored."""
     out: Dict[str, np.ndarray] = {}
     fallback = []
     with open(path, 'rb') as fh:
-        mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
-        with zipfile.ZipFile(fh) as zf:
-            infos = zf.infolist()
-    for info in infos:
-        name = info.filename[:-4] if info.filename.endswith('.npy') else info.filename
-        if info.compress_type != zipfile.ZIP_STORED:
+        try:
+            # every member is read by whoever loads a container: map the pages in one go instead of one fault per 4 KB (a third of dm_events_merge's
+            # time on a 60-byte-per-event table that comes out of the page cache)
+            mm = mmap.mmap(fh.fileno(), 0, flags=mmap.MAP_SHARED | getattr(mmap, 'MAP_POPULATE', 0), prot=mmap.PROT_READ)
+        except (ValueError, OSError):
+            mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        infos = _central_directory(mm)
+        if infos is None:
+            with zipfile.ZipFile(fh) as zf:
+                infos = [(i.filename, i.compress_type, i.header_offset) for i in zf.infolist()]
+    for filename, method, ho in infos:
+        name = filename[:-4] if filename.endswith('.npy') else filename
+        if method != zipfile.ZIP_STORED:
             fallback.append(name)
             continue
-        ho = info.header_offset
         if mm[ho:ho + 4] != b'PK\x03\x04':
             fallback.append(name)
             continue

@@ -287,7 +287,8 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                 from . import signal as dmsignal
                 normalizer = dmsignal.SignalNormalizer(int(moptions.get('device', 0)))
             ids, id_src, raw_parts, raw_offs, ev_offs = [], [], [], [0], [0]
-            cols = {k: [] for k in ('mean', 'stdv', 'start', 'length', 'base')}
+            merges = []                     # per container that was merged: the arguments of its dm_events_merge call (kept alive), for _fallback_values
+            opened = []
             for f5f in raw_files:
                 try:
                     z = npzmap.load(f5f)
@@ -298,26 +299,32 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                     eo = _c_arr(z['ev_off'], np.int64)
                     if len(eo) != n + 1:
                         raise ValueError('event offsets of a damaged container')
-                    ne = int(eo[-1])
                     ms = _c_arr(z['ev_model_state'], z['ev_model_state'].dtype)
-                    mev_off = np.empty(n + 1, np.int64)
-                    m_mean, m_stdv = np.empty(ne, np.float32), np.empty(ne, np.float32)
-                    m_start, m_len, m_base = np.empty(ne, np.uint64), np.empty(ne, np.uint64), np.empty(ne, 'S1')
                     args = [_c_arr(z['ev_mean'], np.float64), _c_arr(z['ev_stdv'], np.float64), _c_arr(z['ev_start'], np.uint64),
                             _c_arr(z['ev_length'], np.uint64)]
                     mv = _c_arr(z['ev_move'], np.int64)
-                    got = lib.dm_events_merge(n, min(len(a) for a in args + [mv, ms]), eo.ctypes.data, args[0].ctypes.data, args[1].ctypes.data, args[2].ctypes.data, args[3].ctypes.data,
-                                              ms.ctypes.data, ms.dtype.itemsize // 4, mv.ctypes.data, mev_off.ctypes.data, m_mean.ctypes.data,
-                                              m_stdv.ctypes.data, m_start.ctypes.data, m_len.ctypes.data, m_base.ctypes.data)
-                    if got < 0:
-                        raise _lib.DeepModHipError(_lib.last_error())
                     ro = _c_arr(z['raw_off'], np.int64)
                     if len(ro) != n + 1 or ro[0] != 0 or (np.diff(ro) < 0).any() or ro[-1] > len(z['raw']):
                         raise ValueError('signal offsets of a damaged container')
+                    opened.append((f5f, z, meta, n, eo, max(int(eo[-1]), 0), ms, args, mv, ro))
                 except Exception:
                     out.errors["Cannot open fast5 or other errors"].append(f5f)
                     print("Cannot open fast5 or other errors: {}".format(f5f))
+            # the merged event tables of the whole batch, written in place container after container (no per-container pieces to concatenate)
+            cap_ev = sum(o[5] for o in opened)
+            m_start, m_len, m_base = np.empty(max(cap_ev, 1), np.uint64), np.empty(max(cap_ev, 1), np.uint64), np.empty(max(cap_ev, 1), 'S1')
+            w = 0
+            for f5f, z, meta, n, eo, ne, ms, args, mv, ro in opened:
+                mev_off = np.empty(n + 1, np.int64)
+                # (the basecaller's mean / stdv are merged later and only if a read of the batch has an empty event: _fallback_values)
+                margs = (n, min(len(a) for a in args + [mv, ms]), eo.ctypes.data, args[0].ctypes.data, args[1].ctypes.data, args[2].ctypes.data, args[3].ctypes.data,
+                         ms.ctypes.data, ms.dtype.itemsize // 4, mv.ctypes.data, mev_off.ctypes.data)
+                got = lib.dm_events_merge(*margs, None, None, m_start.ctypes.data + 8 * w, m_len.ctypes.data + 8 * w, m_base.ctypes.data + w)
+                if got < 0:             # offsets that decrease or run past the table: a damaged container, the batch goes on without it
+                    out.errors["Cannot open fast5 or other errors"].append(f5f)
+                    print("Cannot open fast5 or other errors: {}".format(f5f))
                     continue
+                merges.append((margs, ne, got, w, (eo, ms, mv, mev_off, args)))
                 per_read = mev_off[1:] - mev_off[:-1]
                 for i, m in enumerate(meta):
                     rid = m['read_id'].replace(" ", ":::").replace("\t", "|||")
@@ -329,14 +336,25 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                 raw_parts.append(z['raw'][:int(ro[-1])])          # samples behind the last read's end would shift every later container's offsets
                 raw_offs.extend((raw_offs[-1] + ro[1:]).tolist())
                 ev_offs.extend((ev_offs[-1] + mev_off[1:]).tolist())
-                cols['mean'].append(m_mean[:got]); cols['stdv'].append(m_stdv[:got]); cols['start'].append(m_start[:got])
-                cols['length'].append(m_len[:got]); cols['base'].append(m_base[:got])
+                w += got
             t1 = time.perf_counter()
             out.timing['load'] += t1 - t0
             if ids:
                 cat = lambda parts, dt: np.concatenate(parts) if len(parts) > 1 else _c_arr(parts[0], dt)
-                m_mean, m_stdv = cat(cols['mean'], np.float32), cat(cols['stdv'], np.float32)
-                m_start, m_len, m_base = cat(cols['start'], np.uint64), cat(cols['length'], np.uint64), cat(cols['base'], 'S1')
+                m_start, m_len, m_base = m_start[:w], m_len[:w], m_base[:w]
+                m_mean = m_stdv = None
+
+                def _fallback_values():
+                    """The basecaller's mean / stdv of every merged event of the batch (getEvent's rounding): needed only for events at or behind a read's
+                    first empty event - the containers are merged once more, this time with the value columns."""
+                    mm_, ms_ = np.empty(max(w, 1), np.float32), np.empty(max(w, 1), np.float32)
+                    for margs, ne, got, at, _keep in merges:
+                        a_, b_ = np.empty(ne, np.float32), np.empty(ne, np.float32)
+                        scratch = (np.empty(ne, np.uint64), np.empty(ne, np.uint64), np.empty(ne, 'S1'))
+                        if lib.dm_events_merge(*margs, a_.ctypes.data, b_.ctypes.data, scratch[0].ctypes.data, scratch[1].ctypes.data, scratch[2].ctypes.data) != got:
+                            raise _lib.DeepModHipError('dm_events_merge: ' + _lib.last_error())
+                        mm_[at:at + got], ms_[at:at + got] = a_[:got], b_[:got]
+                    return mm_[:w], ms_[:w]
                 raw_off, mev_off = np.array(raw_offs, np.int64), np.array(ev_offs, np.int64)
                 # resident form (round 6): a batch of raw containers only, whose rows are built on the device anyway - the signal request is POSTED
                 # (samples + event tables into the server's request file, no wait) and its statistics never come back: the feeder needs only
@@ -350,12 +368,14 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                         first_empty = np.empty(len(raw_off) - 1, np.int64)
                         _lib.check(lib.dm_signal_plan_batch(len(raw_off) - 1, raw_off.ctypes.data, mev_off.ctypes.data, m_start.ctypes.data, m_len.ctypes.data,
                                                             first_empty.ctypes.data))
-                        needs_fb = bool((first_empty < (mev_off[1:] - mev_off[:-1])).any())
-                        out.sig = normalizer.post_arrays(raw_parts, raw_off, m_start, m_len, mev_off, first_empty, m_mean if needs_fb else None,
-                                                         m_stdv if needs_fb else None)
+                        if bool((first_empty < (mev_off[1:] - mev_off[:-1])).any()):
+                            m_mean, m_stdv = _fallback_values()
+                        out.sig = normalizer.post_arrays(raw_parts, raw_off, m_start, m_len, mev_off, first_empty, m_mean, m_stdv)
                         s_mean = s_stdv = None
                     else:
                         s_mean, s_stdv, first_empty = normalizer.event_stats_arrays(raw_parts, raw_off, m_start, m_len, mev_off)
+                        if bool((np.asarray(first_empty) < (mev_off[1:] - mev_off[:-1])).any()):
+                            m_mean, m_stdv = _fallback_values()
                 except _lib.DeepModHipError:
                     # a read the batched signal call cannot take (events covering no signal): the per-read Python path reports it
                     lib.dm_rows_destroy(h)
@@ -417,8 +437,9 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
                     keep.extend([flag, pos1, rlen, cidx, ev_read, skip, cig_b, seq_b, ref_ptr, ref_len, cig_ptr, seq_ptr, mev_off, m_mean, m_stdv,
                                  m_len, m_base, s_mean, s_stdv, first_empty, rg_c, rg_lo, rg_hi])
                     _lib.check(lib.dm_rows_add_raw(h, nrec, flag.ctypes.data, pos1.ctypes.data, cig_ptr, seq_ptr, rlen.ctypes.data, cidx.ctypes.data,
-                                                   ev_read.ctypes.data, skip.ctypes.data, nct, ref_ptr, ref_len.ctypes.data, len(mev_off) - 1, len(m_mean), mev_off.ctypes.data,
-                                                   m_mean.ctypes.data, m_stdv.ctypes.data, m_len.ctypes.data, m_base.ctypes.data,
+                                                   ev_read.ctypes.data, skip.ctypes.data, nct, ref_ptr, ref_len.ctypes.data, len(mev_off) - 1, len(m_len), mev_off.ctypes.data,
+                                                   None if m_mean is None else m_mean.ctypes.data, None if m_stdv is None else m_stdv.ctypes.data,
+                                                   m_len.ctypes.data, m_base.ctypes.data,
                                                    None if s_mean is None else s_mean.ctypes.data, None if s_stdv is None else s_stdv.ctypes.data,
                                                    first_empty.ctypes.data, len(region), rg_c.ctypes.data, rg_lo.ctypes.data, rg_hi.ctypes.data))
                     srcs.extend(f5data[q][3] for q, _ in recs)

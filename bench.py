@@ -690,7 +690,7 @@ def main():
                                     "on one persistent dm_comm: rank r is left with the merged counters of positions [r, r + 1) * ceil(L / N)",
                                     reduce_bytes_per_rank=12 * CONTIG_LEN, per_rank=per_rank,
                                     measured_on_hardware_with_more_than_one_rank=bool(world > 1 and os.environ.get("DM_BENCH_ONE_DEVICE") != "1" and not os.environ.get("DEEPMOD_RCCL_LIBRARY")),
-                                    collective_library=os.environ.get("DEEPMOD_RCCL_LIBRARY") or "librccl", rccl_error=None, host_fed_all_ranks=host_fed,
+                                    collective_library="%s (ncclGetVersion %d)" % dmcomm.rccl_info(), rccl_error=None, host_fed_all_ranks=host_fed,
                                     note="`collectives` / `bytes` count one untimed warm-up merge of the same size and the timed one")
         elif control is not None:
             out["multi_gpu"] = {"collective": "NOT RUN: RCCL could not be set up, the final merge of the counters was skipped (barriers and the "

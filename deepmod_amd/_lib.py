@@ -73,6 +73,7 @@ SIGNATURES = [
     ("dm_summary_sync", _c.c_int, [_vp]),
     ("dm_summary_grow", _c.c_int, [_vp, _i64]),
     ("dm_rccl_unique_id", _c.c_int, [_vp]),
+    ("dm_rccl_info", _c.c_int, [_c.c_char_p, _c.c_int, _c.POINTER(_c.c_int)]),
     ("dm_comm_create", _vp, [_c.c_int, _vp, _c.c_int, _c.c_int]),
     ("dm_comm_destroy", None, [_vp]),
     ("dm_comm_rank", _c.c_int, [_vp]),

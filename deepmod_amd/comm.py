@@ -29,6 +29,14 @@ def rccl_unique_id() -> bytes:
     return buf.raw
 
 
+def rccl_info():
+    """(path of the collective library this process bound, ncclGetVersion code - 22707 = 2.27.7) - binds it on first use (dm_rccl_info)."""
+    buf = ctypes.create_string_buffer(1024)
+    version = ctypes.c_int(0)
+    _lib.check(_lib.load().dm_rccl_info(buf, len(buf), ctypes.byref(version)))
+    return buf.value.decode('utf-8', 'replace'), int(version.value)
+
+
 class FileRendezvous:
     """Byte / JSON exchange between the ranks of one run through files in a directory every rank can see (the run's
     output folder).  Writes are atomic (tmp + rename); readers poll."""

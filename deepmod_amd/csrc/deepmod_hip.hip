@@ -4,6 +4,7 @@
 #include "kernels.h"
 
 #include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -14,6 +15,7 @@
 #include <string>
 #include <utility>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/deepmod_hip.h"
@@ -1330,30 +1332,26 @@ int dm_cluster_predict(dm_cluster* c, const float* x, int64_t n, float* out) {
 
 // ---- RCCL, loaded lazily so single-GPU users never need it ---------------------------------
 namespace {
-struct NcclId {
-    char internal[128];
-};
-typedef int (*fn_getid)(NcclId*);
-typedef int (*fn_init)(void**, int, NcclId, int);
-typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
-typedef int (*fn_reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
-typedef int (*fn_reducescatter)(const void*, void*, size_t, int, int, void*, hipStream_t);
-typedef int (*fn_destroy)(void*);
-typedef const char* (*fn_errstr)(int);
-typedef int (*fn_group)(void);
+// The library is found with dlopen (a one-GPU user never needs it, and DEEPMOD_RCCL_LIBRARY may name a site build), but every type, enumerator and
+// prototype is RCCL's own, from <rccl/rccl.h>: a drift between what is called here and what the library exports is a compile error in this file -
+// and in tests/shim/shmccl.cpp, which defines the same functions against the same header - not a surprise on the first eight-rank run.
+static_assert(sizeof(ncclUniqueId) == 128 && NCCL_UNIQUE_ID_BYTES == 128, "the C ABI hands the RCCL id around as 128 bytes (dm_rccl_unique_id)");
 struct Rccl {
     void* h = nullptr;
-    fn_getid getid = nullptr;
-    fn_init init = nullptr;
-    fn_allreduce allreduce = nullptr;
-    fn_reduce reduce = nullptr;
-    fn_reducescatter reducescatter = nullptr;
-    fn_destroy destroy = nullptr;
-    fn_errstr errstr = nullptr;
-    fn_group group_start = nullptr, group_end = nullptr;      // optional: one launch for the three counter arrays of a reduce-scatter
+    std::string path;                                  // what dlopen was given
+    int version = 0;                                   // ncclGetVersion, 0 if the library has none
+    decltype(&ncclGetUniqueId) getid = nullptr;
+    decltype(&ncclCommInitRank) init = nullptr;
+    decltype(&ncclAllReduce) allreduce = nullptr;
+    decltype(&ncclReduce) reduce = nullptr;
+    decltype(&ncclReduceScatter) reducescatter = nullptr;
+    decltype(&ncclCommDestroy) destroy = nullptr;
+    decltype(&ncclGetErrorString) errstr = nullptr;
+    decltype(&ncclGetVersion) getversion = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;   // optional: one launch for the three counter arrays of a reduce-scatter
+    decltype(&ncclGroupEnd) group_end = nullptr;
 };
 Rccl g_rccl;
-constexpr int NCCL_INT32 = 2, NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_MAX = 2;   // ncclDataType_t / ncclRedOp_t values
 
 int load_rccl() {
     if (g_rccl.h) return DM_OK;
@@ -1365,45 +1363,67 @@ int load_rccl() {
     if (named && *named) {
         h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
         if (!h) return fail(DM_ERCCL, "cannot dlopen DEEPMOD_RCCL_LIBRARY=%s: %s", named, dlerror());
+        g_rccl.path = named;
     }
     for (const char* nm : names) {
         if (h) break;
         h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (h) g_rccl.path = nm;
     }
     if (!h) return fail(DM_ERCCL, "cannot dlopen librccl: %s", dlerror());
-    g_rccl.getid = (fn_getid)dlsym(h, "ncclGetUniqueId");
-    g_rccl.init = (fn_init)dlsym(h, "ncclCommInitRank");
-    g_rccl.allreduce = (fn_allreduce)dlsym(h, "ncclAllReduce");
-    g_rccl.reduce = (fn_reduce)dlsym(h, "ncclReduce");
-    g_rccl.reducescatter = (fn_reducescatter)dlsym(h, "ncclReduceScatter");
-    g_rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
-    g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
-    g_rccl.group_start = (fn_group)dlsym(h, "ncclGroupStart");
-    g_rccl.group_end = (fn_group)dlsym(h, "ncclGroupEnd");
+    auto bind = [h](const char* name, auto& fn) { fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(h, name)); };
+    bind("ncclGetUniqueId", g_rccl.getid);
+    bind("ncclCommInitRank", g_rccl.init);
+    bind("ncclAllReduce", g_rccl.allreduce);
+    bind("ncclReduce", g_rccl.reduce);
+    bind("ncclReduceScatter", g_rccl.reducescatter);
+    bind("ncclCommDestroy", g_rccl.destroy);
+    bind("ncclGetErrorString", g_rccl.errstr);
+    bind("ncclGetVersion", g_rccl.getversion);
+    bind("ncclGroupStart", g_rccl.group_start);
+    bind("ncclGroupEnd", g_rccl.group_end);
     if (!g_rccl.getid || !g_rccl.init || !g_rccl.allreduce || !g_rccl.reduce || !g_rccl.destroy)
         return fail(DM_ERCCL, "librccl is missing required symbols");
+    if (g_rccl.getversion && g_rccl.getversion(&g_rccl.version) != ncclSuccess) g_rccl.version = 0;
+    {   // the file the loader really mapped (librccl.so.1 -> /opt/rocm-7.2.0/lib/librccl.so.1.0...): what a run's log should name
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(g_rccl.getid), &info) && info.dli_fname && *info.dli_fname) g_rccl.path = info.dli_fname;
+    }
     g_rccl.h = h;
     return DM_OK;
 }
-const char* rccl_err(int e) { return g_rccl.errstr ? g_rccl.errstr(e) : "error"; }
+const char* rccl_err(ncclResult_t e) { return g_rccl.errstr ? g_rccl.errstr(e) : "error"; }
 }  // namespace
 
 struct dm_comm {
     int device = 0, rank = 0, nranks = 1;
-    void* comm = nullptr;          // ncclComm_t
+    ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     double* d_scalar = nullptr;    // one device double for barrier / max
     int64_t reduces = 0;           // collectives issued (dm_comm_stats)
     int64_t reduced_bytes = 0;
 };
 
+// Which collective library this process bound (loading it if that has not happened yet): the file the loader mapped and ncclGetVersion's code
+// (e.g. 22207 = 2.22.7; 0 if the library has no such entry).  What `detect --gpus N` prints at the start of a multi-GPU run.
+int dm_rccl_info(char* path, int path_len, int* version) {
+    int rc = load_rccl();
+    if (rc) return rc;
+    if (path && path_len > 0) {
+        std::strncpy(path, g_rccl.path.c_str(), size_t(path_len) - 1);
+        path[path_len - 1] = 0;
+    }
+    if (version) *version = g_rccl.version;
+    return DM_OK;
+}
+
 int dm_rccl_unique_id(void* out128) {
     if (!out128) return fail(DM_EINVAL, "null id buffer");
     int rc = load_rccl();
     if (rc) return rc;
-    NcclId id;
-    int e = g_rccl.getid(&id);
-    if (e) return fail(DM_ERCCL, "ncclGetUniqueId: %s", rccl_err(e));
+    ncclUniqueId id;
+    ncclResult_t e = g_rccl.getid(&id);
+    if (e != ncclSuccess) return fail(DM_ERCCL, "ncclGetUniqueId: %s", rccl_err(e));
     std::memcpy(out128, &id, 128);
     return DM_OK;
 }
@@ -1422,7 +1442,7 @@ dm_comm* dm_comm_create(int device, const void* unique_id128, int rank, int nran
     c->device = device;
     c->rank = rank;
     c->nranks = nranks;
-    NcclId id;
+    ncclUniqueId id;
     std::memcpy(&id, unique_id128, 128);
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc(&c->d_scalar, sizeof(double)) == hipSuccess;
@@ -1431,8 +1451,8 @@ dm_comm* dm_comm_create(int device, const void* unique_id128, int rank, int nran
         dm_comm_destroy(c);
         return nullptr;
     }
-    int e = g_rccl.init(&c->comm, nranks, id, rank);       // collective over all ranks: every rank calls it once
-    if (e) {
+    ncclResult_t e = g_rccl.init(&c->comm, nranks, id, rank);       // collective over all ranks: every rank calls it once
+    if (e != ncclSuccess) {
         fail(DM_ERCCL, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, rccl_err(e));
         c->comm = nullptr;
         dm_comm_destroy(c);
@@ -1467,8 +1487,8 @@ int dm_comm_max_f64(dm_comm* c, double* value) {
     HIP_TRY(hipSetDevice(c->device));
     double v = value ? *value : 0.0;
     HIP_TRY(hipMemcpyAsync(c->d_scalar, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
-    int e = g_rccl.allreduce(c->d_scalar, c->d_scalar, 1, NCCL_FLOAT64, NCCL_MAX, c->comm, c->stream);
-    if (e) return fail(DM_ERCCL, "ncclAllReduce(max): %s", rccl_err(e));
+    ncclResult_t e = g_rccl.allreduce(c->d_scalar, c->d_scalar, 1, ncclFloat64, ncclMax, c->comm, c->stream);
+    if (e != ncclSuccess) return fail(DM_ERCCL, "ncclAllReduce(max): %s", rccl_err(e));
     HIP_TRY(hipMemcpyAsync(&v, c->d_scalar, sizeof v, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (value) *value = v;
@@ -1487,9 +1507,9 @@ int dm_summary_reduce(dm_summary* s, dm_comm* c, int root) {
     if (s->follow) HIP_TRY(hipStreamSynchronize(s->follow->stream));   // adds queued on the classifier's stream
     HIP_TRY(hipStreamSynchronize(s->stream));
     const size_t count = size_t(3) * s->length;
-    int e = root >= 0 ? g_rccl.reduce(s->d_counts, s->d_counts, count, NCCL_INT32, NCCL_SUM, root, c->comm, c->stream)
-                      : g_rccl.allreduce(s->d_counts, s->d_counts, count, NCCL_INT32, NCCL_SUM, c->comm, c->stream);
-    if (e) return fail(DM_ERCCL, "%s: %s", root >= 0 ? "ncclReduce" : "ncclAllReduce", rccl_err(e));
+    ncclResult_t e = root >= 0 ? g_rccl.reduce(s->d_counts, s->d_counts, count, ncclInt32, ncclSum, root, c->comm, c->stream)
+                      : g_rccl.allreduce(s->d_counts, s->d_counts, count, ncclInt32, ncclSum, c->comm, c->stream);
+    if (e != ncclSuccess) return fail(DM_ERCCL, "%s: %s", root >= 0 ? "ncclReduce" : "ncclAllReduce", rccl_err(e));
     HIP_TRY(hipStreamSynchronize(c->stream));
     ++c->reduces;
     c->reduced_bytes += int64_t(count) * 4;
@@ -1547,20 +1567,20 @@ int dm_summary_reduce_scatter(dm_summary* s, dm_comm* c, int64_t* first, int64_t
     // the three counter arrays as ONE group where librccl has the group calls (one fused launch per rank instead of three)
     const bool grouped = g_rccl.group_start && g_rccl.group_end;
     if (grouped) {
-        int e = g_rccl.group_start();
-        if (e) return fail(DM_ERCCL, "ncclGroupStart: %s", rccl_err(e));
+        ncclResult_t e = g_rccl.group_start();
+        if (e != ncclSuccess) return fail(DM_ERCCL, "ncclGroupStart: %s", rccl_err(e));
     }
-    int err = 0;
-    for (int k = 0; k < 3 && !err; ++k) {
+    ncclResult_t err = ncclSuccess;
+    for (int k = 0; k < 3 && err == ncclSuccess; ++k) {
         // the send buffer of array k is read up to nranks * chunk <= length + nranks - 1 positions: past `length` that is the head of
         // the next array (or the allocation's slack) - sums of positions that do not exist, never looked at
-        err = g_rccl.reducescatter(s->d_counts + k * s->length, s->d_slice + k * s->slice_chunk, size_t(chunk), NCCL_INT32, NCCL_SUM, c->comm, c->stream);
+        err = g_rccl.reducescatter(s->d_counts + k * s->length, s->d_slice + k * s->slice_chunk, size_t(chunk), ncclInt32, ncclSum, c->comm, c->stream);
     }
     if (grouped) {
-        const int e = g_rccl.group_end();              // always closed, also after a failed call inside the group
-        if (!err) err = e;
+        const ncclResult_t e = g_rccl.group_end();     // always closed, also after a failed call inside the group
+        if (err == ncclSuccess) err = e;
     }
-    if (err) return fail(DM_ERCCL, "ncclReduceScatter: %s", rccl_err(err));
+    if (err != ncclSuccess) return fail(DM_ERCCL, "ncclReduceScatter: %s", rccl_err(err));
     HIP_TRY(hipStreamSynchronize(c->stream));
     ++c->reduces;
     c->reduced_bytes += int64_t(3) * s->length * 4;

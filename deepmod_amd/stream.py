@@ -1735,6 +1735,9 @@ def _stream_rank_body(moptions, rank, world, device, work, result_q, feeders, fe
     communicator = None
     if world > 1:
         communicator = dmcomm.Communicator.from_rendezvous(device, rdv)
+        if rank == 0 and moptions.get('outLevel', 2) <= 1:      # --outLevel 0 / 1: which collective library merges the counters of this run
+            path, version = dmcomm.rccl_info()
+            print('RCCL: %d ranks over %s (ncclGetVersion %d%s)' % (world, path, version, '; DEEPMOD_RCCL_LIBRARY' if os.environ.get('DEEPMOD_RCCL_LIBRARY') else ''), flush=True)
     use_procs = feeder_procs > 0 and hasattr(work, 'get')
     backend = None if use_procs else HipBackend(moptions, device)       # with feeder processes: created once they are running
     eng = StreamEngine(moptions, backend, rank, world)

@@ -241,6 +241,8 @@ int dm_summary_grow(dm_summary* s, int64_t new_length);
  * that), which is how the N > 1 calls below are tested on a one-GPU box.  A path that cannot be loaded is an error (DM_ERCCL). */
 typedef struct dm_comm dm_comm;
 int dm_rccl_unique_id(void* out128);
+/* the collective library this process bound (path the loader mapped, ncclGetVersion code; loads it on first use) */
+int dm_rccl_info(char* path, int path_len, int* version);
 dm_comm* dm_comm_create(int device, const void* unique_id128, int rank, int nranks);
 void dm_comm_destroy(dm_comm* c);
 int dm_comm_rank(const dm_comm* c);

@@ -109,4 +109,4 @@ def test_bench_eight_ranks_merge_through_the_collective_calls(shim_env):
     assert "ncclReduceScatter" in mg["collective"] and mg["collectives"] == 2
     assert [r["rank"] for r in mg["per_rank"]] == list(range(world))
     assert out["summary_check"]["touch"] == sum(r["slice_sums"][0] for r in mg["per_rank"]) > 0
-    assert mg["measured_on_hardware_with_more_than_one_rank"] is False and mg["collective_library"].endswith("libshmccl.so")
+    assert mg["measured_on_hardware_with_more_than_one_rank"] is False and "libshmccl.so (ncclGetVersion" in mg["collective_library"]

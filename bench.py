@@ -43,7 +43,7 @@ PRECISIONS = {
                            "3 x 3 + 2; N = 100 exactly; the zero-state k32-steps of step 0 skipped; round 4: 28,350) = 26.2 MFLOP per "
                            "window = 2.94 matrix FLOP per algorithmic FLOP, so frac <= 0.34 by construction; back-to-back MFMAs on real operand bits "
                            "sustain 1.4-1.75 PF on this part at its 1,400 W limit (profiles/r02/README.md); the 32x32x16 form of rounds 2-3 "
-                           "(3.09 issued per algorithmic, DM_OPT_F16X3_SHAPE = 32) is timed beside it in extras.shape_ab",
+                           "(3.09 issued per algorithmic; tools/experiments/f16s since round 6) measured 8-9 % slower in the same process (profiles/r05/shape_ab.txt)",
               "issued_per_algorithmic": 25600 * 16384 * 2 / 32.0 / FLOP_PER_WINDOW},
     "f16i8": {"peak": 2500.0, "kernel": "lstm16q::bilstm_f16q_kernel<1>", "dtype": "f16+i8",
               "label": "OPT-IN, REDUCED PRECISION: split-f16 MFMA with both cross terms of every product as one int8 MFMA (v_mfma_i32_16x16x64_i8 "
@@ -51,7 +51,7 @@ PRECISIONS = {
                        "(the default kernel: 9e-6) - not a substitute for the default where the tolerance is binding",
               "peak_note": "priced against the dense 16-bit peak 2.5 PF like the default: per 32 windows and direction the kernel issues 17,800 "
                            "MFMAs of 16 cycles instead of 25,600 (the mixed k32-step keeps its three f16 products in one MFMA) = "
-                           "2.04 matrix units per algorithmic unit; the 32x32x16 form of round 3 (DM_OPT_F16X3_SHAPE = 32) is ~5 % slower",
+                           "2.04 matrix units per algorithmic unit; the 32x32x16 form of round 3 (tools/experiments/f16s) was ~5 % slower",
               "issued_per_algorithmic": 17800 * 16384 * 2 / 32.0 / FLOP_PER_WINDOW},
     "f32": {"peak": 157.3, "kernel": "lstm32::bilstm_f32_kernel", "dtype": "f32", "label": "fp32 MFMA",
             "peak_note": "v_mfma_f32_16x16x4_f32 dense fp32, 157.3 TF"},
@@ -148,15 +148,23 @@ def cpu_gemm_baseline(weights, sample, cores):
     return out
 
 
-KERNEL_SOURCES = {"f16x3": ["lstm_f16q.hip.inc"], "f16i8": ["lstm_f16q.hip.inc"], "f32": ["lstm_f32.hip.inc"]}
+# every file a classifier kernel is compiled from (its translation unit, what that includes, the interface header) - VERDICT r05 weak 9a: the
+# default kernel also compiles the shared helpers and the unit's launch / packing code, an edit there must mark a committed profile stale too
+KERNEL_SOURCES = {"f16x3": ["kern_f16q0.hip", "lstm_f16q.hip.inc", "lstm_common.hip.inc", "kernels.h"],
+                  "f16i8": ["kern_f16q1.hip", "kern_f16q0.hip", "lstm_f16q.hip.inc", "lstm_common.hip.inc", "kernels.h"],
+                  "f32": ["kern_f32.hip", "lstm_f32.hip.inc", "kernels.h"]}
 
 
 def kernel_source_sha(precision):
-    """Hash of the classifier kernel's source: a PMC summary is only valid for the kernel it was collected on."""
+    """Hash of everything the classifier kernel of `precision` is built from - its sources (KERNEL_SOURCES) and the compiler flags of
+    __graft_entry__.HIPCC_FLAGS: a PMC summary is only valid for the kernel it was collected on."""
     import hashlib
+    import __graft_entry__ as ge
     h = hashlib.sha256()
     for f in KERNEL_SOURCES[precision]:
+        h.update(f.encode() + b"\0")
         h.update(open(os.path.join(ROOT, "deepmod_amd", "csrc", f), "rb").read())
+    h.update(" ".join(ge.HIPCC_FLAGS).encode())
     return h.hexdigest()[:16]
 
 
@@ -205,7 +213,7 @@ def power_evidence(precision):
         if precision.startswith("f16x3"):
             out["note"] = ("the split-f16 kernels run at or near the package power limit with the shader clock held at ~2.0-2.2 GHz; "
                            "back-to-back f16 MFMAs on real operand bits sustain 1,400-1,650 TFLOP/s on this part (clock 1.36-1.49 GHz) "
-                           "and 1,200 with a VALU / LDS filler mix like this kernel's (profiles/%s/ubench_mfma32_fill.txt)" % rnd)
+                           "and 1,200 with a VALU / LDS filler mix like this kernel's (profiles/r02/ubench_mfma32_fill.txt)")
         return out
     return None
 
@@ -288,7 +296,7 @@ def extras(m, _lib, model, precision, x_dev0, x_host0, prob_dev, cls_dev, reps=4
     m.set_precision(precision)
     # the two MFMA shapes behind DM_PREC_F16X3 on THIS box, alternating in this process: per switch SETUP_LAUNCHES
     # untimed launches, then 64 timed ones (HIP events), four alternations; the driver's box decides which shape is the default
-    if precision == "f16x3":
+    if precision == "f16x3" and m.get_info(_lib.DM_INFO_HAS_F16S):      # (experiment builds only since round 6: DM_WITH_F16S=1, tools/experiments/f16s)
         try:
             ab = {16: [], 32: []}
             for rep in range(4):
@@ -698,7 +706,13 @@ def main():
                                 "rccl_error": comm_error, "per_rank": per_rank, "host_fed_all_ranks": host_fed, "measured_on_hardware_with_more_than_one_rank": bool(world > 1 and os.environ.get("DM_BENCH_ONE_DEVICE") != "1")}
         if world == 1 and plog is not None and plog.available:
             try:
-                out["roofline"]["power"]["steady"] = steady_power_leg(m, model, _lib, plog, x_dev[0], prob_dev, cls_dev)
+                st = out["roofline"]["power"]["steady"] = steady_power_leg(m, model, _lib, plog, x_dev[0], prob_dev, cls_dev)
+                # the K timed steps are ~30 ms, shorter than the firmware's power averaging: the same launches in the steady state of the box, beside it
+                ach = BATCH * FLOP_PER_WINDOW / (st["avg_launch_ms"] * 1e-3) / 1e12
+                out["roofline"]["steady"] = {"avg_launch_ms": st["avg_launch_ms"], "launches": st["launches"], "achieved": ach, "frac": ach / P["peak"],
+                                             "windows_per_s_kernel": BATCH / (st["avg_launch_ms"] * 1e-3),
+                                             "note": "the same kernel on the same batch back to back for 1.5 s after the timed region (HIP events per launch): `frac` "
+                                                     "above is the contract's K timed steps, this is the box's steady state - both are measured, neither is `value`"}
             except Exception as exc:
                 out["roofline"]["power"]["steady"] = {"error": repr(exc)}
         if plog is not None:

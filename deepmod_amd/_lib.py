@@ -19,12 +19,13 @@ DM_OPT_PROFILE = 1
 DM_OPT_PRECISION = 2
 DM_OPT_ASYNC = 3
 DM_OPT_RESERVED_CUS = 4
-DM_OPT_F16X3_SHAPE = 5   # 16 (default: 16x16x32 MFMAs) | 32 (the 32x32x16 kernel of rounds 2-3)
+DM_OPT_F16X3_SHAPE = 5   # 16 (the product: 16x16x32 MFMAs) | 32 (experiment builds only: the 32x32x16 kernels of rounds 2-3)
 DM_PREC_F32 = 0
 DM_PREC_F16X3 = 1
 DM_PREC_F16I8 = 3      # opt-in, reduced precision: int8 cross terms (2 issued matrix units per product instead of 3; worst window of 1e6 1.1e-4 instead of 9e-6 at weight scale 4)
 DM_PREC_F16X3_ROLES = 2   # round-4 experiment (matrix / cell wave pairs, bit-identical to F16X3): only in a library built with -DDM_WITH_F16X3_ROLES (DM_INFO_HAS_F16X3_ROLES)
 DM_INFO_PRECISION, DM_INFO_F16_REPRESENTABLE, DM_INFO_F16_LENGTH_SHIFT, DM_INFO_DEVICE, DM_INFO_HAS_F16X3_ROLES = 1, 2, 3, 4, 5
+DM_INFO_HAS_F16S = 6         # 1: experiment build with the 32x32x16 kernels of rounds 2-3 (DM_WITH_F16S=1)
 DM_OK, DM_EINVAL, DM_EDEVICE, DM_ENOMEM, DM_ESTATE, DM_ERCCL, DM_ERANGE = 0, -1, -2, -3, -4, -5, -6
 (DM_MAP_STATUS, DM_MAP_N_ROWS, DM_MAP_LEFTCLIP, DM_MAP_RIGHTCLIP, DM_MAP_EV_LO, DM_MAP_EV_HI, DM_MAP_FIRST_MATCH_POS,
  DM_MAP_LAST_MATCH_POS, DM_MAP_NUM_INSERT, DM_MAP_NUM_DELETE, DM_MAP_NUM_MISMATCH, DM_MAP_STRAND, DM_MAP_POS_AFTER_CLIP,

@@ -190,9 +190,9 @@ struct dm_model {
     float* d_wpack = nullptr;
     float* d_bpack = nullptr;
     float* d_hpack = nullptr;
-    unsigned char* d_wpack16s = nullptr;  // split-f16 weights in the tile-major layout (DM_PREC_F16X3)
+    unsigned char* d_wpack16s = nullptr;  // experiment builds (DM_WITH_F16S): split-f16 weights in the tile-major layout of the 32x32x16 kernels
     unsigned char* d_wpack16q = nullptr;  // the same weights in the 16x16x32 layout (lstm_f16q.hip.inc)
-    bool f16_q = false;                   // DM_PREC_F16X3 runs lstm16q::bilstm_f16q_kernel (16x16x32 MFMAs) instead of lstm16s::bilstm_f16s_kernel<0>
+    bool f16_q = true;                    // the split-f16 modes run lstm16q::bilstm_f16q_kernel (16x16x32 MFMAs): always, except in an experiment build with DM_OPT_F16X3_SHAPE = 32
     unsigned char* d_wpack16i = nullptr;  // the same layout with int8 cross-term records (DM_PREC_F16I8)
     float i8s[24] = {};                   // its fold scales [dir][layer][gate kind]
     unsigned char* d_wpack16qi = nullptr; // DM_PREC_F16I8 in the 16x16x32 layout (lstm16q::bilstm_f16q_kernel<1>: int8 16x16x64 cross terms)
@@ -222,6 +222,7 @@ struct dm_model {
     int precision = DM_PREC_F16X3;        // default: fastest mode that meets the 1e-4 probability tolerance
     float f16_max_abs = 0.0f;             // largest |packed weight| (x exponent scale)
     bool f16_ok = true;                   // every packed weight is a finite f16 (checked at create; else the default is DM_PREC_F32)
+    bool i8_calibrated = false;           // DM_PREC_F16I8 was selected by dm_model_calibrate_i8 (for the MFMA shape of that moment)
     int len_shift = 0;                    // DM_INFO_F16_LENGTH_SHIFT
     // DM_ERANGE bookkeeping: host-mapped words the split-f16 kernels set on an input they cannot represent.  A launch writes
     // the CURRENT slot; dm_model_mark(i) ties the current slot to marker i and moves on to a free one, so that
@@ -311,38 +312,48 @@ int ensure_f16_common(dm_model* m) {
 }
 
 // one weight pack per (shape, mode), built on first use
-int ensure_pack(dm_model* m, unsigned char*& d_pack, const Packed16& P, hipError_t prepared) {
+int ensure_pack(unsigned char*& d_pack, const Packed16& P, hipError_t prepared) {
     if (prepared != hipSuccess) return fail(DM_EDEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(prepared));
-    HIP_TRY(hipMalloc(&d_pack, P.w.size()));
-    HIP_TRY(hipMemcpy(d_pack, P.w.data(), P.w.size(), hipMemcpyHostToDevice));
+    // the model's pointer is set only once the pack is on the device: a failed copy must not leave a non-null pointer to uninitialised memory
+    // behind (the next launch would take it for a finished pack)
+    unsigned char* d = nullptr;
+    HIP_TRY(hipMalloc(&d, P.w.size()));
+    const hipError_t e = hipMemcpy(d, P.w.data(), P.w.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail(DM_EDEVICE, "uploading a weight pack failed: %s", hipGetErrorString(e));
+    }
+    d_pack = d;
     return DM_OK;
 }
+#ifdef DM_WITH_F16S
 int ensure_f16s(dm_model* m) {
     if (m->d_wpack16s) return DM_OK;
     int rc = ensure_f16_common(m);
     if (rc) return rc;
-    rc = ensure_pack(m, m->d_wpack16s, dmk::pack_weights_f16s(m->host_weights.data()), dmk::f16s_prepare(0));
+    rc = ensure_pack(m->d_wpack16s, dmk::pack_weights_f16s(m->host_weights.data()), dmk::f16s_prepare(0));
     if (rc) return rc;
     if (dmk::f16s_has_roles() && dmk::f16s_prepare(2) != hipSuccess) return fail(DM_EDEVICE, "the roles kernel cannot be prepared");
     return DM_OK;
-}
-int ensure_f16q(dm_model* m) {
-    if (m->d_wpack16q) return DM_OK;
-    int rc = ensure_f16_common(m);
-    if (rc) return rc;
-    return ensure_pack(m, m->d_wpack16q, dmk::pack_weights_f16q(m->host_weights.data()), dmk::f16q_prepare(0));
-}
-int ensure_f16qi(dm_model* m) {
-    if (m->d_wpack16qi) return DM_OK;
-    int rc = ensure_f16_common(m);
-    if (rc) return rc;
-    return ensure_pack(m, m->d_wpack16qi, dmk::pack_weights_f16q(m->host_weights.data(), true, m->i8s_q), dmk::f16q_prepare(1));
 }
 int ensure_f16i8(dm_model* m) {
     if (m->d_wpack16i) return DM_OK;
     int rc = ensure_f16_common(m);
     if (rc) return rc;
-    return ensure_pack(m, m->d_wpack16i, dmk::pack_weights_f16s(m->host_weights.data(), true, m->i8s), dmk::f16s_prepare(1));
+    return ensure_pack(m->d_wpack16i, dmk::pack_weights_f16s(m->host_weights.data(), true, m->i8s), dmk::f16s_prepare(1));
+}
+#endif
+int ensure_f16q(dm_model* m) {
+    if (m->d_wpack16q) return DM_OK;
+    int rc = ensure_f16_common(m);
+    if (rc) return rc;
+    return ensure_pack(m->d_wpack16q, dmk::pack_weights_f16q(m->host_weights.data()), dmk::f16q_prepare(0));
+}
+int ensure_f16qi(dm_model* m) {
+    if (m->d_wpack16qi) return DM_OK;
+    int rc = ensure_f16_common(m);
+    if (rc) return rc;
+    return ensure_pack(m->d_wpack16qi, dmk::pack_weights_f16q(m->host_weights.data(), true, m->i8s_q), dmk::f16q_prepare(1));
 }
 
 
@@ -378,7 +389,12 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         const bool i8 = m->precision == DM_PREC_F16I8;
         const bool q16 = m->precision == DM_PREC_F16X3 && m->f16_q;
         const bool qi8 = i8 && m->f16_q;                 // DM_OPT_F16X3_SHAPE picks the MFMA shape of both modes
+#ifdef DM_WITH_F16S
         int rc = qi8 ? ensure_f16qi(m) : i8 ? ensure_f16i8(m) : (q16 ? ensure_f16q(m) : ensure_f16s(m));
+#else
+        if (!m->f16_q || m->precision == DM_PREC_F16X3_ROLES) return fail(DM_EINVAL, "the 32x32x16 kernels are not part of this build (tools/experiments/f16s: DM_WITH_F16S=1)");
+        int rc = qi8 ? ensure_f16qi(m) : ensure_f16q(m);
+#endif
         if (rc) return rc;
         dmk::F16Args a;
         a.wpack = qi8 ? m->d_wpack16qi : i8 ? m->d_wpack16i : q16 ? m->d_wpack16q : m->d_wpack16s;
@@ -393,7 +409,9 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         a.range_flag = m->d_range_flag + m->range_cur;
         a.i8s = qi8 ? m->i8s_q : i8 ? m->i8s : nullptr;
         if (q16 || qi8) dmk::f16q_launch(qi8 ? 1 : 0, a, grid, m->stream);
+#ifdef DM_WITH_F16S
         else dmk::f16s_launch(i8 ? 1 : (m->precision == DM_PREC_F16X3_ROLES ? 2 : 0), a, grid, m->stream);
+#endif
     } else {
         dmk::F32Args a;
         a.wpack = m->d_wpack;
@@ -573,14 +591,15 @@ int model_init(dm_model* m, const float* weights) {
     m->range_cur = 0;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_range_flag), m->range_flag, 0));
     {   // trained kernels far outside the usual range cannot be split into f16 halves: such a model runs the fp32 kernel
-        Packed16 P16 = dmk::pack_weights_f16s(weights);
+        Packed16 P16 = dmk::pack_weights_f16q(weights);
         m->f16_ok = P16.finite && P16.max_abs <= 65504.0f;
         m->f16_max_abs = P16.finite ? P16.max_abs : INFINITY;
         m->len_shift = P16.len_shift;
         m->precision = m->f16_ok ? DM_PREC_F16X3 : DM_PREC_F32;
     }
-    {   // which kernel runs DM_PREC_F16X3: lstm_f16q.hip.inc (16x16x32 MFMAs; default since round 4: 1.2-2.6 % less time per launch, profiles/r04/shape_ab.txt)
-        // or, with DM_F16X3_SHAPE=32 in the environment at model creation, lstm_f16s.hip.inc (32x32x16: rounds 2-3; also the int8 mode's kernel)
+    m->f16_q = true;
+#ifdef DM_WITH_F16S
+    {   // experiment builds: DM_F16X3_SHAPE=32 in the environment at model creation runs the split-f16 modes on the 32x32x16 kernels of rounds 2-3
         const char* e = std::getenv("DM_F16X3_SHAPE");
         m->f16_q = DM_F16X3_SHAPE_DEFAULT == 16;
         if (e && *e) {
@@ -589,6 +608,7 @@ int model_init(dm_model* m, const float* weights) {
             else std::fprintf(stderr, "deepmod_hip: DM_F16X3_SHAPE=%s ignored (16 or 32); the default shape %d stays\n", e, DM_F16X3_SHAPE_DEFAULT);
         }
     }
+#endif
     return DM_OK;
 }
 
@@ -702,6 +722,15 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
             return DM_OK;
         case DM_OPT_F16X3_SHAPE:
             if (value != 16 && value != 32) return fail(DM_EINVAL, "DM_OPT_F16X3_SHAPE: %lld (16 or 32)", (long long)value);
+#ifndef DM_WITH_F16S
+            if (value == 32)
+                return fail(DM_EINVAL, "DM_OPT_F16X3_SHAPE = 32 (the 32x32x16 kernels of rounds 2-3) is not part of this build: tools/experiments/f16s, DM_WITH_F16S=1");
+#endif
+            if ((value == 16) != m->f16_q && m->precision == DM_PREC_F16I8 && m->i8_calibrated) {
+                // the calibration gate looked at the int8 kernel of the OTHER shape (its own pack, its own quantisation): the selection does not carry over
+                m->precision = DM_PREC_F16X3;
+                m->i8_calibrated = false;
+            }
             m->f16_q = value == 16;
             return DM_OK;
         case DM_OPT_RESERVED_CUS:
@@ -711,6 +740,7 @@ int dm_model_set_option(dm_model* m, int key, int64_t value) {
         case DM_OPT_PRECISION:
             if (value != DM_PREC_F32 && value != DM_PREC_F16X3 && value != DM_PREC_F16X3_ROLES && value != DM_PREC_F16I8)
                 return fail(DM_EINVAL, "unknown precision %lld", (long long)value);
+            m->i8_calibrated = false;      // an explicit choice of the caller
 #ifndef DM_WITH_F16X3_ROLES
             if (value == DM_PREC_F16X3_ROLES)
                 return fail(DM_EINVAL, "DM_PREC_F16X3_ROLES (the wave-pair experiment kernel of round 4) is not part of this build; rebuild with -DDM_WITH_F16X3_ROLES");
@@ -827,7 +857,8 @@ __device__ __forceinline__ uint64_t mix(uint64_t z) {
     return z ^ (z >> 31);
 }
 __device__ __forceinline__ float unit(uint64_t h) { return ((float)(h >> 41) + 0.5f) * (1.0f / 8388608.0f); }      // (0, 1): 23 bits + 1/2, exact in fp32
-// wide = 0: the configs[1] distribution.  wide = 1 (every second batch, round 5): READ-SHAPED tails the nominal draw hardly ever produces - event
+// wide = 0: the configs[1] distribution.  wide = 1 / 2 (all windows / every second window of a batch - the gate's draw since round 6; round 5 alternated
+// whole batches, so a call of one batch never saw it): READ-SHAPED tails the nominal draw hardly ever produces - event
 // means uniform over the whole clip range with 6 % exactly on the clip (+-5: the MAD-normalised signal is clipped there), standard deviations
 // up to 9x, event lengths log-uniform from 1 to 30,000 samples (stalled events) - so that the gate sees the inputs a real run can feed
 __global__ void windows_kernel(float* __restrict__ x, long long n_rows, uint64_t seed, int wide) {
@@ -844,7 +875,7 @@ __global__ void windows_kernel(float* __restrict__ x, long long n_rows, uint64_t
     r[4] = rintf(fminf(fmaxf(1.2f * z0, -5.0f), 5.0f) * 1000.0f) * 0.001f;
     r[5] = rintf(fabsf(0.25f + 0.15f * z1) * 1000.0f) * 0.001f;
     r[6] = 1.0f + floorf(logf(unit(h3)) * (1.0f / -0.12783337f));      // ln(1 - 0.12)
-    if (wide) {
+    if (wide == 2 ? int((i / DM_WINDOW) & 1) : wide) {        // 2: every second WINDOW of the batch (a call of a single batch sees both draws)
         const uint64_t h4 = mix(h3), h5 = mix(h4);
         const float u = unit(h4), v = unit(h5);
         r[4] = u < 0.03f ? -5.0f : (u > 0.97f ? 5.0f : rintf((10.0f * unit(h1) - 5.0f) * 1000.0f) * 0.001f);
@@ -898,7 +929,7 @@ int dm_model_calibrate_i8(dm_model* m, int64_t n_windows, double bound, double* 
     for (int64_t done = 0, batch = 0; done < n_windows && rc == DM_OK; done += B, ++batch) {
         const int64_t n = std::min<int64_t>(B, n_windows - done);
         const long long rows = (long long)n * DM_WINDOW;
-        hipLaunchKernelGGL(calib::windows_kernel, dim3(unsigned((rows + 255) / 256)), dim3(256), 0, m->stream, d_x, rows, uint64_t(0x5EEDC0DEull + batch), int(batch & 1));
+        hipLaunchKernelGGL(calib::windows_kernel, dim3(unsigned((rows + 255) / 256)), dim3(256), 0, m->stream, d_x, rows, uint64_t(0x5EEDC0DEull + batch), 2);
         m->precision = DM_PREC_F32;
         rc = launch_bilstm(m, d_x, (long long)DM_WINDOW * DM_NFEAT, n, d_pa, nullptr);
         m->precision = DM_PREC_F16I8;
@@ -918,7 +949,10 @@ int dm_model_calibrate_i8(dm_model* m, int64_t n_windows, double bound, double* 
     float err;
     std::memcpy(&err, &bits, 4);
     if (max_abs_dp) *max_abs_dp = double(err);
-    if (double(err) <= bound && m->precision == DM_PREC_F16X3) m->precision = DM_PREC_F16I8;
+    if (double(err) <= bound && m->precision == DM_PREC_F16X3) {
+        m->precision = DM_PREC_F16I8;
+        m->i8_calibrated = true;
+    }
     if (selected) *selected = m->precision == DM_PREC_F16I8 ? 1 : 0;      // the mode the model runs after the call
     if (m->precision != DM_PREC_F16I8) {                    // a refused model does not keep the int8 weight packs (1.7 MB)
         (void)hipFree(m->d_wpack16i);
@@ -953,6 +987,13 @@ int dm_model_get_info(dm_model* m, int key, int64_t* value) {
         case DM_INFO_F16_REPRESENTABLE: *value = m->f16_ok ? 1 : 0; return DM_OK;
         case DM_INFO_F16_LENGTH_SHIFT: *value = m->len_shift; return DM_OK;
         case DM_INFO_DEVICE: *value = m->device; return DM_OK;
+        case DM_INFO_HAS_F16S:
+#ifdef DM_WITH_F16S
+            *value = 1;
+#else
+            *value = 0;
+#endif
+            return DM_OK;
         case DM_INFO_HAS_F16X3_ROLES:
 #ifdef DM_WITH_F16X3_ROLES
             *value = 1;

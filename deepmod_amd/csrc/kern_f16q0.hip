@@ -2,13 +2,13 @@
 // instantiations (kern_f16q1.hip holds <1>: the two compile side by side).
 #include "kernels.h"
 #include <utility>
-#include "lstm_f16s.hip.inc"
+#include "lstm_common.hip.inc"
 #include "lstm_f16q.hip.inc"
 
 static_assert(lstm16q::TILE_M == dmk::TILE_M, "work item size");
 
 namespace {
-inline void fill(lstm16s::Params& p, const dmk::F16Args& a) {
+inline void fill(lstmc::Params& p, const dmk::F16Args& a) {
     p.wpack = a.wpack;
     p.wpack_i8 = a.wpack;
     p.hpack = a.hpack;
@@ -153,7 +153,7 @@ hipError_t f16q_prepare(int mm) {
 }
 void f16q_launch(int mm, const F16Args& a, int grid, hipStream_t stream) {
     if (mm == 1) return f16q1_launch(a, grid, stream);
-    lstm16s::Params p;
+    lstmc::Params p;
     fill(p, a);
     hipLaunchKernelGGL(lstm16q::bilstm_f16q_kernel<0>, dim3(grid), dim3(lstm16q::THREADS), lstm16q::LDS_BYTES, stream, p);
 }

@@ -1,11 +1,11 @@
 // kern_f16q1.hip - translation unit of lstm16q::bilstm_f16q_kernel<1> (DM_PREC_F16I8 on the 16x16 MFMA shape, round 5).
 #include "kernels.h"
 #include <utility>
-#include "lstm_f16s.hip.inc"
+#include "lstm_common.hip.inc"
 #include "lstm_f16q.hip.inc"
 
 namespace {
-inline void fill(lstm16s::Params& p, const dmk::F16Args& a) {
+inline void fill(lstmc::Params& p, const dmk::F16Args& a) {
     p.wpack = a.wpack;
     p.wpack_i8 = a.wpack;
     p.hpack = a.hpack;
@@ -29,7 +29,7 @@ hipError_t f16q1_prepare() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16q::bilstm_f16q_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lstm16q::LDS_BYTES_I8));
 }
 void f16q1_launch(const F16Args& a, int grid, hipStream_t stream) {
-    lstm16s::Params p;
+    lstmc::Params p;
     fill(p, a);
     hipLaunchKernelGGL(lstm16q::bilstm_f16q_kernel<1>, dim3(grid), dim3(lstm16q::THREADS), lstm16q::LDS_BYTES_I8, stream, p);
 }

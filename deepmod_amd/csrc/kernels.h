@@ -1,5 +1,5 @@
-// kernels.h - what the translation units of libdeepmod_hip.so share (round 5: the library is built from five of them in parallel - the
-// three classifier kernel families compile for minutes each, the host code around them in seconds).  Each kernel family lives in ONE
+// kernels.h - what the translation units of libdeepmod_hip.so share (the library is built from four of them in parallel - the classifier kernels
+// compile for minutes each, the host code around them in seconds; round 6: the 32x32x16 kernels of rounds 2-3 are a fifth unit of EXPERIMENT builds only).  Each kernel family lives in ONE
 // translation unit (kern_*.hip) with its weight packer and a launch wrapper; deepmod_hip.hip (C ABI, host runtime, the small kernels) sees
 // only this header.  Host-side interface only: no kernel, no device type in here.
 #pragma once
@@ -16,7 +16,7 @@
     defined(DM16S_ABL_NOLDSA) || defined(DM16S_ADIST) || defined(DM16S_ALO_TRUNC) || defined(DM16S_PRE) || defined(DM_ABL_NOBAR) ||                \
     defined(DM_ABL_NODMA) || defined(DM_ABL_NOEPI) || defined(DM_ABL_NOSEQ) || defined(DM_TIMING) || defined(DM_TRACE) || defined(DM_TRACE2) ||   \
     defined(DM_WLO_TRUNC_ENV) || defined(DM_WLO_TRUNC_DEFAULT) || defined(DM_WITH_F16X3_ROLES) || defined(DM16R_DMA_M) ||                         \
-    defined(DM_F16X3_SHAPE_DEFAULT) || defined(DM_WAVES) || defined(DM_MT)
+    defined(DM_F16X3_SHAPE_DEFAULT) || defined(DM_WAVES) || defined(DM_MT) || defined(DM_WITH_F16S)
 #define DM_ANY_EXPERIMENT_SWITCH 1
 #ifndef DM_EXPERIMENT
 #error "an ablation / experiment macro is defined without -DDM_EXPERIMENT: timing-only kernels must not be built into the product by a stray -D"
@@ -25,6 +25,10 @@
 #define DM_ANY_EXPERIMENT_SWITCH 0
 #endif
 
+
+#if defined(DM_WITH_F16X3_ROLES) && !defined(DM_WITH_F16S)
+#error "the roles experiment lives in the translation unit of the 32x32x16 kernels: build it with -DDM_WITH_F16S as well"
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -114,11 +118,14 @@ hipError_t f32_prepare();                                          // once per p
 void f32_launch(const F32Args& a, int grid, hipStream_t stream);
 size_t f32_scratch_floats_per_wg();
 int f32_waves();
-// kern_f16s.hip: lstm16s::bilstm_f16s_kernel<mm> (mm 0: three f16 products, 1: int8 cross terms, 2: the roles experiment when built)
+#ifdef DM_WITH_F16S
+// tools/experiments/f16s/kern_f16s.hip (experiment builds only, round 6): lstm16s::bilstm_f16s_kernel<mm> - the 32x32x16 kernels of rounds 2-3
+// (mm 0: three f16 products, 1: int8 cross terms, 2: the roles experiment when built)
 Packed16 pack_weights_f16s(const float* flat, bool int8 = false, float* i8s = nullptr);
 hipError_t f16s_prepare(int mm);
 void f16s_launch(int mm, const F16Args& a, int grid, hipStream_t stream);
 bool f16s_has_roles();
+#endif
 // kern_f16q0.hip / kern_f16q1.hip: lstm16q::bilstm_f16q_kernel<mm>
 Packed16 pack_weights_f16q(const float* flat, bool int8 = false, float* i8s = nullptr);
 hipError_t f16q_prepare(int mm);

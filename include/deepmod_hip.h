@@ -60,17 +60,17 @@ extern "C" {
 #define DM_OPT_RESERVED_CUS 4 /* n in [0, CUs / 2]: the classifier's persistent grid uses CUs - n workgroups (one per CU), so that
                               small kernels of OTHER streams (the signal stage of the streaming worker) run beside a classifier
                               launch instead of waiting for it to drain.  Default 0. */
-#define DM_OPT_F16X3_SHAPE 5  /* which build of the DM_PREC_F16X3 / DM_PREC_F16I8 kernels runs: 16 (default: v_mfma_f32_16x16x32_f16 and
-                              v_mfma_i32_16x16x64_i8, lstm_f16q.hip.inc) or 32 (v_mfma_f32_32x32x16_f16 / v_mfma_i32_32x32x32_i8,
-                              lstm_f16s.hip.inc: rounds 2-3; ~8 % / ~5 % slower on full launches since round 5).  Same arithmetic, another
-                              summation order: results differ in the last bits.  The environment variable DM_F16X3_SHAPE = 16 | 32 sets
-                              the initial value at dm_model_create (anything else is ignored with a warning). */
+#define DM_OPT_F16X3_SHAPE 5  /* MFMA shape of the DM_PREC_F16X3 / DM_PREC_F16I8 kernels.  16 = the product (v_mfma_f32_16x16x32_f16 and
+                              v_mfma_i32_16x16x64_i8, csrc/lstm_f16q.hip.inc); 32 (v_mfma_f32_32x32x16_f16 / v_mfma_i32_32x32x32_i8: the kernels of
+                              rounds 2-3, ~8 % / ~5 % slower, tools/experiments/f16s since round 6) exists only in an experiment build
+                              (DM_WITH_F16S=1, DM_INFO_HAS_F16S) - a product library answers 32 with DM_EINVAL.  Same arithmetic, another
+                              summation order: results differ in the last bits.  A model whose DM_PREC_F16I8 was selected by
+                              dm_model_calibrate_i8 goes back to DM_PREC_F16X3 when the shape changes (the gate saw the other kernel). */
 #define DM_PREC_F32 0      /* fp32 MFMA (v_mfma_f32_16x16x4_f32): fp32 products, the TF graph's own arithmetic */
 #define DM_PREC_F16X3 1    /* split-f16 MFMA: every fp32 operand = hi + lo f16, 3 products per fp32 product, fp32
                               accumulation; max |dp| vs the oracle 1e-6 .. 2e-6 (tolerance of the path: 1e-4), ~3x faster.
                               Step-major kernel: weights and feature rows in, logits out, the state of the three layers never
-                              leaves the chip.  Two builds of it: csrc/lstm_f16q.hip.inc on v_mfma_f32_16x16x32_f16 (the one that
-                              runs since round 4) and csrc/lstm_f16s.hip.inc on v_mfma_f32_32x32x16_f16 (DM_OPT_F16X3_SHAPE).
+                              leaves the chip: csrc/lstm_f16q.hip.inc on v_mfma_f32_16x16x32_f16.
                               Range contract (nothing is clamped silently):
                                 * weights: every kernel / bias value times its exponent scale (<= 2.886) must be a finite f16
                                   (|w| <~ 22,700).  A model that violates this is created with DM_PREC_F32 as its default and
@@ -102,6 +102,7 @@ extern "C" {
 #define DM_INFO_F16_LENGTH_SHIFT 3   /* k above */
 #define DM_INFO_DEVICE 4
 #define DM_INFO_HAS_F16X3_ROLES 5    /* 1 if the library was built with the wave-pair experiment kernel */
+#define DM_INFO_HAS_F16S 6           /* 1 if the library was built with the 32x32x16 kernels of rounds 2-3 (experiment builds: DM_WITH_F16S=1) */
 
 typedef struct dm_model dm_model;
 typedef struct dm_summary dm_summary;

@@ -502,61 +502,67 @@ def test_int8_mode_is_selected_per_model_by_the_calibration_gate(gpu_device):
     m.close()
 
 
-def test_both_mfma_shapes_behind_the_default_precision(gpu_device):
-    """DM_PREC_F16X3 runs lstm16q::bilstm_f16q_kernel (16x16x32 MFMAs, default since round 4) or, with DM_F16X3_SHAPE=32 at model creation,
-    lstm16s::bilstm_f16s_kernel<0> (32x32x16, rounds 2-3): the same three-product arithmetic in a different summation order - both inside the
-    path's tolerance against the oracle with an order of magnitude to spare, on ragged sizes, three weight sets and out-of-range event lengths."""
+def _shapes(m):
+    """MFMA shapes this library can run the split-f16 modes on: 16 (the product) and, in an experiment build (DM_WITH_F16S=1), 32."""
     from deepmod_amd import _lib
+    return (16, 32) if m.get_info(_lib.DM_INFO_HAS_F16S) else (16,)
 
-    def make(w, shape):
-        m = model.BiLSTMModel(w, device=gpu_device)
-        m.set_option(_lib.DM_OPT_F16X3_SHAPE, shape)
-        return m
-    m = make(synth.synthetic_weights(21, 1.0), 16)
+
+def test_mfma_shape_option_of_the_split_f16_modes(gpu_device):
+    """Round 6: the product runs DM_PREC_F16X3 / DM_PREC_F16I8 on the 16x16x32 / 16x16x64 MFMAs only (lstm16q::bilstm_f16q_kernel<0 | 1>); the
+    32x32x16 kernels of rounds 2-3 moved to tools/experiments/f16s and a product library refuses DM_OPT_F16X3_SHAPE = 32.  In an experiment build
+    (DM_WITH_F16S=1) both shapes are held to the oracle and to each other as in rounds 4-5: the same arithmetic in a different summation order -
+    inside the path's tolerance with an order of magnitude to spare (int8 mode: inside its documented bound) on ragged sizes, three weight sets
+    and out-of-range event lengths."""
+    from deepmod_amd import _lib
+    m = model.BiLSTMModel(synth.synthetic_weights(21, 1.0), device=gpu_device)
+    shapes = _shapes(m)
     with pytest.raises(_lib.DeepModHipError):
         m.set_option(_lib.DM_OPT_F16X3_SHAPE, 8)
+    m.set_option(_lib.DM_OPT_F16X3_SHAPE, 16)
+    if shapes == (16,):
+        with pytest.raises(_lib.DeepModHipError) as exc:
+            m.set_option(_lib.DM_OPT_F16X3_SHAPE, 32)
+        assert 'not part of this build' in str(exc.value)
+        with pytest.raises(_lib.DeepModHipError):
+            m.set_option(_lib.DM_OPT_PRECISION, _lib.DM_PREC_F16X3_ROLES)
     m.close()
-    for w in (synth.synthetic_weights(21, 1.0), synth.synthetic_weights(26, 4.0), trained_like_weights()):
-        m16, m32 = make(w, 16), make(w, 32)
-        for n in (1, 15, 16, 17, 31, 32, 33, 127, 129, 4097, 20000):
-            x = synth.synthetic_windows(n, seed=300 + n)
-            if n == 4097:
-                x[::7, :, 6] = 3.0e6                      # event lengths beyond the f16 range: the rescaled slot of lane group 3
-            ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
-            p16, c16 = m16.predict_windows(x)
-            p32, c32 = m32.predict_windows(x)
-            assert _check(p16, c16, ref_prob, ref_cls) <= 3e-5
-            assert _check(p32, c32, ref_prob, ref_cls) <= 3e-5
-            assert np.abs(p16 - p32).max() <= 3e-5
-        m16.close()
-        m32.close()
+    for prec, cases in (("f16x3", ((synth.synthetic_weights(21, 1.0), 3e-5, TOL), (synth.synthetic_weights(26, 4.0), 3e-5, TOL), (trained_like_weights(), 3e-5, TOL))),
+                        ("f16i8", ((synth.synthetic_weights(21, 1.0), 5e-5, TOL_I8), (synth.synthetic_weights(26, 4.0), TOL_I8, TOL_I8), (trained_like_weights(), 5e-5, TOL_I8)))):
+        for w, bound, tol in cases:
+            ms = []
+            for shape in shapes:
+                mm = model.BiLSTMModel(w, device=gpu_device, precision=prec)
+                mm.set_option(_lib.DM_OPT_F16X3_SHAPE, shape)
+                ms.append(mm)
+            for n in (1, 15, 16, 17, 31, 32, 33, 127, 129, 4097, 20000):
+                x = synth.synthetic_windows(n, seed=300 + n)
+                if n == 4097:
+                    x[::7, :, 6] = 3.0e6                      # event lengths beyond the f16 range: the rescaled slot of lane group 3
+                ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
+                got = [mm.predict_windows(x) for mm in ms]
+                for p, c in got:
+                    assert _check(p, c, ref_prob, ref_cls, tol) <= bound
+                if len(got) == 2:
+                    assert np.abs(got[0][0] - got[1][0]).max() <= (3e-5 if prec == "f16x3" else TOL_I8)
+            for mm in ms:
+                mm.close()
 
 
-def test_both_mfma_shapes_behind_the_int8_mode(gpu_device):
-    """DM_PREC_F16I8 runs lstm16q::bilstm_f16q_kernel<1> (v_mfma_i32_16x16x64_i8 cross terms, round 5: the default shape) or, with
-    DM_OPT_F16X3_SHAPE = 32, lstm16s::bilstm_f16s_kernel<1> (v_mfma_i32_32x32x32_i8, round 3): the same reduced-precision arithmetic (int8
-    cross terms, documented bound 2e-4) on ragged sizes, three weight sets and out-of-range event lengths; the two agree with each other
-    inside that bound, and with the oracle's classes away from near ties."""
+def test_calibrated_int8_selection_does_not_survive_a_change_of_the_mfma_shape(gpu_device):
+    """dm_model_calibrate_i8 gates the int8 kernel of the shape of that moment; DM_OPT_F16X3_SHAPE afterwards would run the OTHER shape's
+    int8 kernel (its own pack and quantisation) uncalibrated - the selection now falls back to DM_PREC_F16X3.  (Only an experiment build has a second shape.)"""
     from deepmod_amd import _lib
+    m = model.BiLSTMModel(trained_like_weights(), device=gpu_device)
+    err, selected = m.calibrate_i8()
+    assert selected and m.get_info(_lib.DM_INFO_PRECISION) == _lib.DM_PREC_F16I8
+    m.set_option(_lib.DM_OPT_F16X3_SHAPE, 16)                 # the same shape: nothing changes
+    assert m.get_info(_lib.DM_INFO_PRECISION) == _lib.DM_PREC_F16I8
+    if m.get_info(_lib.DM_INFO_HAS_F16S):
+        m.set_option(_lib.DM_OPT_F16X3_SHAPE, 32)
+        assert m.get_info(_lib.DM_INFO_PRECISION) == _lib.DM_PREC_F16X3
+    m.close()
 
-    def make(w, shape):
-        m = model.BiLSTMModel(w, device=gpu_device, precision="f16i8")
-        m.set_option(_lib.DM_OPT_F16X3_SHAPE, shape)
-        return m
-    for w, bound in ((synth.synthetic_weights(21, 1.0), 5e-5), (synth.synthetic_weights(26, 4.0), TOL_I8), (trained_like_weights(), 5e-5)):
-        m16, m32 = make(w, 16), make(w, 32)
-        for n in (1, 15, 16, 17, 31, 32, 33, 127, 129, 4097, 20000):
-            x = synth.synthetic_windows(n, seed=300 + n)
-            if n == 4097:
-                x[::7, :, 6] = 3.0e6                      # event lengths beyond the f16 range
-            ref_prob, ref_cls = oracle_np.predict_windows_c(w, x)
-            p16, c16 = m16.predict_windows(x)
-            p32, c32 = m32.predict_windows(x)
-            assert _check(p16, c16, ref_prob, ref_cls, TOL_I8) <= bound
-            assert _check(p32, c32, ref_prob, ref_cls, TOL_I8) <= bound
-            assert np.abs(p16 - p32).max() <= TOL_I8
-        m16.close()
-        m32.close()
 
 
 def test_selected_mode_on_read_shaped_rows(gpu_device):

@@ -67,6 +67,9 @@ def build(names):
         out = os.path.join(ABL, "lib_%s.so" % name)
         # any switch needs the umbrella (csrc/kernels.h: a stray -D is a compile error); one object directory per variant
         flags = VARIANTS[name] + (["-DDM_EXPERIMENT"] if VARIANTS[name] else [])
+        # the 32x32x16 kernels (DM16S_* switches, the roles experiment) are a translation unit of experiment builds only since round 6
+        if any(f.startswith(("-DDM16S_", "-DDM_WITH_F16X3_ROLES", "-DDM16R_", "-DDM_WLO_TRUNC")) for f in flags) and "-DDM_WITH_F16S" not in flags:
+            flags = flags + ["-DDM_WITH_F16S"]
         ge.build_library(out, flags, objdir=os.path.join(ABL, "obj_" + name), quiet=True)
         print("built", out)
 

@@ -1,16 +1,17 @@
-// kern_f16s.hip - translation unit of lstm16s::bilstm_f16s_kernel<0 | 1> (the 32x32 MFMA forms of DM_PREC_F16X3 / DM_PREC_F16I8; and, in an
+// kern_f16s.hip (tools/experiments/f16s since round 6: compiled only with DM_WITH_F16S=1) - translation unit of lstm16s::bilstm_f16s_kernel<0 | 1> (the 32x32 MFMA forms of DM_PREC_F16X3 / DM_PREC_F16I8; and, in an
 // experiment build, the roles kernel): the kernels, their weight packer, their launch wrapper.
-#include "kernels.h"
+#include "../../../deepmod_amd/csrc/kernels.h"
 #include <utility>
+#include "../../../deepmod_amd/csrc/lstm_common.hip.inc"
 #include "lstm_f16s.hip.inc"
 #ifdef DM_WITH_F16X3_ROLES   // the matrix / cell wave-pair form of the default kernel (round 4): an experiment build, not part of the product
-#include "../../tools/experiments/f16r/lstm_f16r.hip.inc"
+#include "../f16r/lstm_f16r.hip.inc"
 #endif
 
 static_assert(lstm16s::TILE_M == dmk::TILE_M, "work item size");
 
 namespace {
-inline void fill(lstm16s::Params& p, const dmk::F16Args& a) {
+inline void fill(lstmc::Params& p, const dmk::F16Args& a) {
     p.wpack = a.wpack;
     p.wpack_i8 = a.wpack;
     p.hpack = a.hpack;
@@ -196,7 +197,7 @@ hipError_t f16s_prepare(int mm) {
 #endif
 }
 void f16s_launch(int mm, const F16Args& a, int grid, hipStream_t stream) {
-    lstm16s::Params p;
+    lstmc::Params p;
     fill(p, a);
     if (mm == 0) hipLaunchKernelGGL(lstm16s::bilstm_f16s_kernel<0>, dim3(grid), dim3(lstm16s::THREADS), lstm16s::LDS_BYTES, stream, p);
     else if (mm == 1) hipLaunchKernelGGL(lstm16s::bilstm_f16s_kernel<1>, dim3(grid), dim3(lstm16s::THREADS), lstm16s::LDS_BYTES, stream, p);

@@ -22,11 +22,14 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 LIB = os.path.join(ROOT, "deepmod_amd", "csrc", "libdeepmod_hip.so")
 
 PRODUCT_KERNELS = {
-    "f16q": "_ZN7lstm16q18bilstm_f16q_kernelILi0EEEvN7lstm16s6ParamsE",
-    "f16qi8": "_ZN7lstm16q18bilstm_f16q_kernelILi1EEEvN7lstm16s6ParamsE",
-    "f16s": "_ZN7lstm16s18bilstm_f16s_kernelILi0EEEvNS_6ParamsE",
-    "f16i8": "_ZN7lstm16s18bilstm_f16s_kernelILi1EEEvNS_6ParamsE",
+    "f16q": "_ZN7lstm16q18bilstm_f16q_kernelILi0EEEvN5lstmc6ParamsE",
+    "f16qi8": "_ZN7lstm16q18bilstm_f16q_kernelILi1EEEvN5lstmc6ParamsE",
     "f32": "_ZN6lstm3217bilstm_f32_kernelENS_6ParamsE",
+}
+# experiment builds only (DM_WITH_F16S=1, tools/experiments/f16s): the 32x32x16 kernels of rounds 2-3 - product kernels until round 5
+EXPERIMENT_KERNELS = {
+    "f16s": "_ZN7lstm16s18bilstm_f16s_kernelILi0EEEvN5lstmc6ParamsE",
+    "f16i8": "_ZN7lstm16s18bilstm_f16s_kernelILi1EEEvN5lstmc6ParamsE",
 }
 # (passes of 4 cycles, XDL?) of the MFMAs the product issues.  Wait states before a VALU instruction may read or overwrite the result, as LLVM's
 # GCNHazardRecognizer enforces them for gfx950 (and as hipcc's own output shows: it pads to exactly these): XDL (the 16-bit / 8-bit

@@ -10,7 +10,7 @@
 // the product by accident: without -DDM_EXPERIMENT any of them is a compile error, and dm_build_flags() reports what a library was built with
 // (tests/test_build_guard.py checks the shipped library says "experiment=0").
 #if defined(DM16Q_ABL_NOCELL) || defined(DM16Q_ABL_NODMA) || defined(DM16Q_ABL_MIX1) || defined(DM16Q_ABL_I8T) || defined(DM16Q_ABL_NOBAR) || defined(DM16Q_ABL_NOVMWAIT) || defined(DM16Q_AINIT) || defined(DM16Q_DEBUG_NOP) ||           \
-    defined(DM16Q_NOCHUNK) || defined(DM16Q_NOPN) || defined(DM16Q_PRE) || defined(DM16Q_SNAKE) || defined(DM16Q_TRANS_COST) ||                     \
+    defined(DM16Q_NOCHUNK) || defined(DM16Q_NOPN) || defined(DM16Q_LOPACK) || defined(DM16Q_PRE) || defined(DM16Q_SNAKE) || defined(DM16Q_TRANS_COST) ||                     \
     defined(DM16S_ABL_2PROD) || defined(DM16S_ABL_B64) || defined(DM16S_ABL_LO_ONLY) || defined(DM16S_ABL_MFMA16) ||                              \
     defined(DM16S_ABL_MFMA16_PAD) || defined(DM16S_ABL_NOBAR) || defined(DM16S_ABL_NOCELL) || defined(DM16S_ABL_NODMA) ||                          \
     defined(DM16S_ABL_NOLDSA) || defined(DM16S_ADIST) || defined(DM16S_ALO_TRUNC) || defined(DM16S_PRE) || defined(DM_ABL_NOBAR) ||                \

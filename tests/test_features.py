@@ -89,3 +89,39 @@ def test_compiled_feature_rows_match_reference_get_feature():
         assert np.array_equal(pos[r0 + 100:r0 + 100 + nal], want[100:100 + nal, 0].astype(np.int64)), k     # column 0: the reference position
         r0 += len(want)
     assert r0 == R.value
+
+
+def test_events_merge_rounds_like_numpy_bit_for_bit():
+    """getEvent stores round(mean, 3) / round(stdv, 3) (numpy.round: rint(x * 1000) / 1000 in float64) into '<f4' fields (myDetect.py:241-249).
+    dm_events_merge's rint goes through the 1.5 * 2^52 constant; ADVICE r05: (v + M) - M is +0.0 where numpy gives -0.0 for inputs in (-0.0005, 0) -
+    the sign is put back, so the float32 BITS equal numpy's, also on exact ties (round half to even) and on values beyond the constant's range."""
+    import numpy as np
+    from deepmod_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    special = np.array([-0.0004, -0.00049999, -0.0005, -0.0, 0.0, 0.0004, 0.0005, 0.0015, 0.0025, -0.0015, -0.0025, 1.0005, 2.0015, 123.4565, -123.4565,
+                        1e-300, -1e-300, 4.5e12, -4.5e12, 3e15, -3e15, 0.5 / 1000, 1.5 / 1000, 2.5 / 1000, -2.5 / 1000], np.float64)
+    mean = np.concatenate([special, rng.normal(0, 50, 4000), rng.normal(0, 1e-3, 2000), (rng.integers(-4000, 4000, 2000) + 0.5) / 1000.0])
+    stdv = np.abs(mean[::-1]).copy()
+    n = len(mean)
+    ev_off = np.array([0, n], np.int64)
+    start = np.arange(n, dtype=np.uint64) * 10
+    length = np.full(n, 10, np.uint64)
+    move = np.ones(n, np.int64)
+    ms = np.zeros((n, 5), np.uint32)
+    ms[:, 2] = ord('A')
+    mev_off = np.empty(2, np.int64)
+    m_mean, m_stdv = np.empty(n, np.float32), np.empty(n, np.float32)
+    m_start, m_len, m_base = np.empty(n, np.uint64), np.empty(n, np.uint64), np.empty(n, 'S1')
+    got = lib.dm_events_merge(1, n, ev_off.ctypes.data, mean.ctypes.data, stdv.ctypes.data, start.ctypes.data, length.ctypes.data, ms.ctypes.data, 5,
+                              move.ctypes.data, mev_off.ctypes.data, m_mean.ctypes.data, m_stdv.ctypes.data, m_start.ctypes.data, m_len.ctypes.data, m_base.ctypes.data)
+    assert got == n
+    want_mean, want_stdv = np.round(mean, 3).astype(np.float32), np.round(stdv, 3).astype(np.float32)
+    assert np.array_equal(m_mean.view(np.uint32), want_mean.view(np.uint32)), np.flatnonzero(m_mean.view(np.uint32) != want_mean.view(np.uint32))[:5]
+    assert np.array_equal(m_stdv.view(np.uint32), want_stdv.view(np.uint32))
+    assert np.signbit(m_mean[0]) and m_mean[0] == 0.0                 # -0.0004 -> -0.0, as numpy
+    # the values are optional: without them the call produces the same tables (start, length, base) and never reads mean / stdv
+    s2, l2, b2 = np.empty(n, np.uint64), np.empty(n, np.uint64), np.empty(n, 'S1')
+    assert lib.dm_events_merge(1, n, ev_off.ctypes.data, None, None, start.ctypes.data, length.ctypes.data, ms.ctypes.data, 5, move.ctypes.data,
+                               mev_off.ctypes.data, None, None, s2.ctypes.data, l2.ctypes.data, b2.ctypes.data) == n
+    assert np.array_equal(s2, m_start) and np.array_equal(l2, m_len) and np.array_equal(b2, m_base)

@@ -42,6 +42,8 @@ VARIANTS = {
     "q_novmwait": ["-DDM16Q_ABL_NOVMWAIT"], "q_novmwait_nobar": ["-DDM16Q_ABL_NOVMWAIT", "-DDM16Q_ABL_NOBAR"],      # is the DMA's latency exposed (the wait before the barrier)?
     "q_nobar": ["-DDM16Q_ABL_NOBAR"], "q_nodma": ["-DDM16Q_ABL_NODMA"], "q_nocell": ["-DDM16Q_ABL_NOCELL"], "q_nodma_nobar": ["-DDM16Q_ABL_NODMA", "-DDM16Q_ABL_NOBAR"],      # round 5: where the merged-mixed kernel's time goes (timing only)
     "q_i8t": ["-DDM16Q_ABL_I8T"],        # round 5: timing only - both cross terms of a k32-step as one int8 16x16x64 MFMA (the price of an int8 mode on this shape, before its fold / pack instructions)
+    "q_lopack_mix": ["-DDM16Q_LOPACK=1"],   # round 6: the lo halves packed by v_fma_mixlo / mixhi_f16 (2 instructions fewer per super-tile, bit-identical)
+    "q_lopack_none": ["-DDM16Q_LOPACK=2"],  # round 6: timing only - no lo pack at all (what those two conversions cost)
     "q_mix1": ["-DDM16Q_ABL_MIX1"],      # round 5: the mixed k32-step issued as one product (timing only)
     "q_base": [], "q_pre1": ["-DDM16Q_PRE=1"], "q_pre3": ["-DDM16Q_PRE=3"], "q_ainit": ["-DDM16Q_AINIT"], "q_trans3": ["-DDM16Q_TRANS_COST=3"], "q_trans1": ["-DDM16Q_TRANS_COST=1"],
     "q_nochunk": ["-DDM16Q_NOCHUNK"], "q_nop": ["-DDM16Q_DEBUG_NOP"], "q_nop_nochunk": ["-DDM16Q_DEBUG_NOP", "-DDM16Q_NOCHUNK"],

@@ -111,6 +111,20 @@ def test_detect_cli_on_raw_containers_matches_oracle_pipeline(tmp_path, gpu_devi
     for strand in '+-':
         assert open('%s/rawstream1/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read() == \
             open('%s/raw1/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read()
+    # round 6: that streaming run kept its event statistics on the device (resident form: dm_signal_event_stats_device -> dm_rows_assemble, nothing per
+    # event through the feeders); with DEEPMOD_STATS_ON_DEVICE=0 the statistics take round 5's way through the host - the same BED bytes
+    import re
+    m = re.search(r'event statistics resident on the device for (\d+) of (\d+) rows', res_s.stdout)
+    assert m and int(m.group(1)) == int(m.group(2)) > 0, res_s.stdout[-1500:]
+    cmd_h = list(cmd_s)
+    cmd_h[cmd_h.index('rawstream1')] = 'rawstream_host_stats'
+    res_h = subprocess.run(cmd_h, capture_output=True, text=True, timeout=600, env=dict(os.environ, DEEPMOD_STATS_ON_DEVICE='0'))
+    assert res_h.returncode == 0, res_h.stdout[-1500:] + res_h.stderr[-3000:]
+    m = re.search(r'event statistics resident on the device for (\d+) of (\d+) rows', res_h.stdout)
+    assert m and int(m.group(1)) == 0
+    for strand in '+-':
+        assert open('%s/rawstream_host_stats/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read() == \
+            open('%s/raw1/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read()
 
     genome = readmap.read_fasta(fasta)['chrS']
     classify = lambda x: oracle_np.predict_windows_c(w, np.asarray(x, np.float32))[1]

@@ -373,6 +373,88 @@ def test_resident_form_of_a_raw_batch_equals_the_device_form(tmp_path):
     assert ready.get() is None
 
 
+def test_posted_signal_requests_protocol(tmp_path):
+    """Feeder side of the resident form (stream.RemoteSignalNormalizer.post_arrays): a request is written into one of two alternating request files and
+    queued WITHOUT waiting for statistics; request k may reuse the file of request k - 2 only after the server acknowledged having copied it; the request
+    layout (stream._sig_layout_res) carries first_empty and, only when needed, the fall-back values; a server-side failure surfaces at the next post.
+    GPU process side: stream.SignalResults hands a result to whoever asks for it, before or after it arrives."""
+    import mmap
+    import threading
+    import time
+    from deepmod_amd import _lib
+    requests, answers = queue.Queue(), queue.Queue()
+    norm = stream.RemoteSignalNormalizer(3, str(tmp_path), requests, answers)
+    rng = np.random.default_rng(2)
+
+    def batch(n_reads, n_samples, with_fb):
+        raws = [rng.integers(300, 900, n_samples).astype(np.int16) for _ in range(n_reads)]
+        lens = [rng.integers(3, 12, n_samples // 10).astype(np.uint64) for _ in range(n_reads)]
+        starts = [np.concatenate([[5], 5 + np.cumsum(ln)[:-1]]).astype(np.uint64) for ln in lens]
+        raw_off = np.concatenate([[0], np.cumsum([len(r) for r in raws])]).astype(np.int64)
+        ev_off = np.concatenate([[0], np.cumsum([len(x) for x in lens])]).astype(np.int64)
+        st, ln = np.concatenate(starts), np.concatenate(lens)
+        fe = np.array([len(x) for x in lens], np.int64)
+        fb = (rng.random(len(st)).astype(np.float32), rng.random(len(st)).astype(np.float32)) if with_fb else (None, None)
+        return raws, raw_off, st, ln, ev_off, fe, fb
+
+    def read_request(req):
+        kind, wid, path, size, n, n_raw, n_ev, seq, with_fb = req
+        assert kind == 'res' and wid == 3
+        with open(path, 'r+b') as fh:
+            mm = mmap.mmap(fh.fileno(), size)
+        o = stream._sig_layout_res(n, n_raw, n_ev, with_fb)
+        out = {k: np.frombuffer(mm, dt, cnt, o[k]).copy() for k, dt, cnt in (('raw', np.int16, n_raw), ('raw_off', np.int64, n + 1), ('ev_off', np.int64, n + 1),
+                                                                                ('ev_start', np.uint64, n_ev), ('ev_length', np.uint64, n_ev), ('first_empty', np.int64, n))}
+        if with_fb:
+            out['fb_mean'] = np.frombuffer(mm, np.float32, n_ev, o['fb_mean']).copy()
+        return seq, path, out
+
+    b1, b2, b3 = batch(3, 4000, False), batch(2, 9000, True), batch(2, 700_000, False)
+    k1 = norm.post_arrays(b1[0], b1[1], b1[2], b1[3], b1[4], b1[5])
+    k2 = norm.post_arrays(b2[0], b2[1], b2[2], b2[3], b2[4], b2[5], *b2[6])
+    assert k1 == (3, 1) and k2 == (3, 2) and requests.qsize() == 2          # both queued, nobody waited
+    s1, p1, r1 = read_request(requests.get())
+    s2, p2, r2 = read_request(requests.get())
+    assert (s1, s2) == (1, 2) and p1 != p2
+    assert np.array_equal(r1['raw'], np.concatenate(b1[0])) and np.array_equal(r1['ev_start'], b1[2]) and np.array_equal(r1['first_empty'], b1[5])
+    assert np.array_equal(r2['ev_length'], b2[3]) and np.array_equal(r2['fb_mean'], b2[6][0])
+    # request 3 wants the file of request 1: it blocks until that one is acknowledged
+    done = []
+    th = threading.Thread(target=lambda: done.append(norm.post_arrays(b3[0], b3[1], b3[2], b3[3], b3[4], b3[5])), daemon=True)
+    th.start()
+    time.sleep(0.3)
+    assert not done and requests.empty()
+    answers.put(('ack', 1, None))
+    th.join(timeout=10)
+    assert done == [(3, 3)]
+    s3, p3, r3 = read_request(requests.get())
+    assert s3 == 3 and p3 == p1 and np.array_equal(r3['raw'], np.concatenate(b3[0]))      # the first file again (grown: the batch outgrew it)
+    # a failed acknowledgement (the server could not even copy the request) surfaces at the next post
+    answers.put(('ack', 2, 'signal server: boom'))
+    try:
+        norm.post_arrays(b1[0], b1[1], b1[2], b1[3], b1[4], b1[5])
+        raise AssertionError('the server error must surface')
+    except _lib.DeepModHipError as exc:
+        assert 'boom' in str(exc)
+    norm.close()
+    # the GPU process' registry
+    res = stream.SignalResults()
+    res.put((3, 1), 'block-a', 1, None)
+    assert res.take((3, 1)) == ('block-a', 1, None) and res.pending() == []
+    got = []
+    th = threading.Thread(target=lambda: got.append(res.take((3, 2), timeout=10)), daemon=True)
+    th.start()
+    time.sleep(0.1)
+    res.put((3, 2), None, 0, 'signal stage: failed')
+    th.join(timeout=10)
+    assert got == [(None, 0, 'signal stage: failed')]
+    try:
+        res.take((9, 9), timeout=0.2)
+        raise AssertionError('a result that never arrives must time out')
+    except RuntimeError as exc:
+        assert 'never answered' in str(exc)
+
+
 def test_compact_batch_without_any_base_of_interest(tmp_path):
     """A batch whose reads hold no base of interest at all (an all-T genome, --Base C): feature rows but no window to classify, no
     positions, no extras - through the compiled path, the shared-memory hand-over and the engine (no BED file is written)."""

@@ -8,7 +8,9 @@ from oracle import oracle_np
 z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'trained_like_weights.npz'))
 w = {k.replace('|', '/'): np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
 ms = {'f32': model.BiLSTMModel(w, 0, precision='f32'), 'f16x3': model.BiLSTMModel(w, 0, precision='f16x3'), 'f16i8': model.BiLSTMModel(w, 0, precision='f16i8')}
-m32 = model.BiLSTMModel(w, 0, precision='f16x3'); m32.set_option(_lib.DM_OPT_F16X3_SHAPE, 32); ms['f16x3/32'] = m32
+m32 = model.BiLSTMModel(w, 0, precision='f16x3')
+if m32.get_info(_lib.DM_INFO_HAS_F16S):      # experiment builds only (DM_WITH_F16S=1): the 32x32x16 kernel of rounds 2-3 beside the product kernel
+    m32.set_option(_lib.DM_OPT_F16X3_SHAPE, 32); ms['f16x3/32'] = m32
 n = 8192
 for where in ('centre', 'row 3', 'all rows'):
     for L in (10, 100, 1000, 10000, 30000, 60000):

@@ -239,18 +239,29 @@ def main():
             r['hbm_traffic_GB'] = None if f is None or w is None else round((2 * f + w) * 1024 / 1e9, 3)
         # the signal stage of one worker batch alone on the device (no classifier holding the compute units)
         sdir = tmp + "/prof_signal"
-        res = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", sdir, "--", sys.executable, os.path.abspath(__file__),
+        res = subprocess.run(["rocprofv3", "--kernel-trace", "--memory-copy-trace", "--stats", "--output-format", "csv", "-d", sdir, "--", sys.executable, os.path.abspath(__file__),
                               "--signal-only", src, "22", "20"], capture_output=True, text=True)
         alone = None
         m2 = re.search(r'SIGNAL_ONLY_WORK (\d+) (\d+) (\d+) (\d+)', res.stdout)
         if res.returncode == 0 and m2:
             nr, ns_, ne_, calls = (int(v) for v in m2.groups())
-            arows, _ = kernel_table(sdir, {"samples": ns_ * calls, "merged_events": ne_ * calls, "reads": nr * calls, "rows": 0, "classified": 0})
-            alone = {"request": {"reads": nr, "samples": ns_, "merged_events": ne_, "calls": calls}, "kernels": arows,
+            arows, acopies = kernel_table(sdir, {"samples": ns_ * calls, "merged_events": ne_ * calls, "reads": nr * calls, "rows": 0, "classified": 0})
+            # timeline of one request, averaged over the calls: uploads (samples, event tables, per-read tables), fills (histograms, range, flag), the four
+            # kernels, the few bytes that come back (fallback flags, range flag) - everything on the handle's stream, ONE host wait at the end
+            h2d = acopies.get('MEMORY_COPY_HOST_TO_DEVICE', {"copies": 0, "total_ms": 0.0})
+            d2h = acopies.get('MEMORY_COPY_DEVICE_TO_HOST', {"copies": 0, "total_ms": 0.0})
+            per_call = {"upload_ms": round(h2d["total_ms"] / calls, 4), "uploads": h2d["copies"] // calls,
+                        "upload_bytes": 2 * ns_ + 16 * ne_ + 40 * nr, "download_ms": round(d2h["total_ms"] / calls, 4), "downloads": d2h["copies"] // calls}
+            for r in arows:
+                per_call[r['kernel'] + "_ms"] = round(r['total_ms'] / calls, 4)
+            alone = {"request": {"reads": nr, "samples": ns_, "merged_events": ne_, "calls": calls}, "kernels": arows, "memory_copies": acopies, "timeline_of_one_request_ms": per_call,
                      "line": [ln for ln in res.stdout.splitlines() if ln.startswith('signal-only')]}
             print("signal stage alone on the device (one worker batch, %d calls):" % calls)
             for r in arows:
                 print("%-34s %8d %10.2f %9.1f %9s %9s %8s" % (r['kernel'][:34], r['launches'], r['total_ms'], r['avg_us'], r['algorithmic_GB'], r['achieved_GB_per_s'], r['frac_of_8TBps']))
+            print("timeline of one request (ms, averaged):", json.dumps(per_call))
+            for ln in alone["line"]:
+                print(ln)
         else:
             sys.stderr.write(res.stdout[-1500:] + res.stderr[-1500:])
         report["signal_stage_alone"] = alone

@@ -13,8 +13,8 @@
     then two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) for the HBM traffic of the signal kernels.
     Written to gpurun_out/r06/raw/ (copy what is to be judged into profiles/r06/raw/).
 
-Algorithmic bytes (DESIGN.md): histogram 2 B/sample; order statistics 256 KB/read (the 65,536-bin histogram); value table 512 KB/read written;
-event statistics 2 B/sample + 16 B/event in, 12 B/event out; row assembly 13 B/row in, 28 B/row out; summary 10 B/entry."""
+Algorithmic bytes: histogram 2 B/sample; event statistics 2 B/sample + 16 B/event in, 12 B/event out; row assembly 13 B/row in,
+28 B/row out; summary 10 B/entry; order statistics and value table: the read's own value range (data dependent, not priced)."""
 import csv
 import glob
 import json
@@ -141,7 +141,9 @@ def kernel_table(prof_dir, work):
             d[0] += 1
             d[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     S, E, NR, R, W = work['samples'], work['merged_events'], work['reads'], work['rows'], work['classified']
-    alg = {'signal_hist_batch_kernel': 2 * S, 'signal_norm_batch_kernel': 262144 * NR, 'signal_lut_batch_kernel': 524288 * NR,
+    # (order statistics and value table work on each read's own value range since round 6 - a few thousand of the 65,536 bins, data dependent: no
+    #  fixed algorithmic byte count; their time and measured HBM traffic are reported as they are)
+    alg = {'signal_hist_batch_kernel': 2 * S,
            'event_ev3_batch_kernel': 2 * S + 28 * E, 'event_stats_batch_kernel': 2 * S + 24 * E, 'rows_assemble_kernel': 41 * R,
            'summary_add_kernel': 10 * (W + 0.3 * W), 'head_finish_kernel': 25 * W}
     rows = []

@@ -177,6 +177,48 @@ def test_detect_cli_on_raw_containers_matches_oracle_pipeline(tmp_path, gpu_devi
         assert len(got) > 500
 
 
+def test_raw_reads_with_an_empty_event_and_a_stalled_event_through_the_resident_form(tmp_path, gpu_device):
+    """Round 6: the corners of the resident form through the whole command.  One read gets an event whose slice is EMPTY (index 60 <= 500: the reference's loop
+    stops there and the events from there on keep the basecaller's values, myDetect.py:334-340 - here the fall-back values are merged ON THE DEVICE), another a
+    stalled event of 70,000 samples (beyond the split-f16 kernels' range: its batch takes the fp32 kernel).  The streaming command with the statistics resident
+    on the device, the same command with DEEPMOD_STATS_ON_DEVICE=0 (statistics through the host, round 5's form) and the stored path (per-read prediction
+    files, the reference's shape) must write the same BED bytes."""
+    import re
+    from deepmod_amd import npzmap
+    wrk = tmp_path / 'raw'
+    files, fasta = synth_reads.write_synthetic_raw_run(str(wrk), n_reads=16, reads_per_file=4, genome_len=20000, seed=8, chrom='chrS')
+    z = {k: np.array(v) for k, v in npzmap.load(files[0]).items()}
+    eo, ro = z['ev_off'], z['raw_off']
+    st, ln = np.array(z['ev_start']), np.array(z['ev_length'])
+    st[eo[1] + 60] = int(ro[2] - ro[1]) + 1000              # read 1 of the first container: an empty slice at event 60
+    z['ev_start'] = st
+    npzmap.savez_aligned(files[0], **z)
+    z = {k: np.array(v) for k, v in npzmap.load(files[1]).items()}
+    ln = np.array(z['ev_length'])
+    ln[z['ev_off'][2] + 300] = 70000                          # read 2 of the second container: a stalled event (the slice is clamped at the signal's end)
+    z['ev_length'] = ln
+    npzmap.savez_aligned(files[1], **z)
+    prefix = str(tmp_path / 'model' / 'mod_train_synth')
+    os.makedirs(os.path.dirname(prefix))
+    synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)
+    out = str(tmp_path / 'out')
+    base = [sys.executable, os.path.join(ROOT, 'bin', 'DeepMod.py'), 'detect', '--wrkBase', str(wrk), '--modfile', prefix, '--Ref', fasta, '--outFolder', out,
+            '--threads', '2', '--files_per_thread', '2', '--Base', 'C', '--gpus', '1', '--alignStr', 'minimap2']
+    runs = {}
+    for name, extra, env in (('resident', [], {}), ('hoststats', [], {'DEEPMOD_STATS_ON_DEVICE': '0'}), ('stored', ['--storePred', '1'], {})):
+        res = subprocess.run(base + ['--FileID', name] + extra, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+        runs[name] = res.stdout
+    m = re.search(r'event statistics resident on the device for (\d+) of (\d+) rows', runs['resident'])
+    assert m and int(m.group(1)) == int(m.group(2)) > 0
+    assert 'Streaming detect: 16 reads' in runs['resident'] and 'Streaming detect: 16 reads' in runs['hoststats']
+    for strand in '+-':
+        a = open('%s/resident/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read()
+        assert len(a) > 300
+        assert a == open('%s/hoststats/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read()
+        assert a == open('%s/stored/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read()
+
+
 def test_two_rank_run_that_cannot_build_its_communicator_fails_fast_and_clean(tmp_path, gpu_device):
     """`--gpus 2` with both GPU processes on device 0 (DEEPMOD_ONE_DEVICE=1, a test hook for one-GPU boxes): two real ranks and their
     feeders start, meet at the file rendezvous, and RCCL refuses the communicator (two ranks on one device).  The product has no merge

@@ -58,6 +58,38 @@ def drain(lib, h, n_contigs, compact):
     return ng
 
 
+def drain_resident(lib, h, n_contigs, n_events):
+    """dm_rows_info + dm_rows_device_info + dm_rows_emit_resident (round 6: no per-event values, descriptors that index the signal stage's device block) into
+    exactly sized buffers; every descriptor must stay inside the batch's merged event tables."""
+    R, T, S, nm = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    n = lib.dm_rows_info(h, ctypes.byref(R), ctypes.byref(T), ctypes.byref(S), None, None, 0, ctypes.byref(nm))
+    if n < 0:
+        return n
+    R, T, S = R.value, T.value, S.value
+    ne, nr = ctypes.c_int64(), ctypes.c_int64()
+    ok = lib.dm_rows_device_info(h, ctypes.byref(ne), ctypes.byref(nr))
+    if ok != 1:
+        return 0                                   # no emitted read: nothing to hand over
+    NR = nr.value
+    n_pf = S + (T - R)
+    code, rdesc = np.empty(R, np.uint8), np.empty((NR, 4), np.int64)
+    pos, flags, sel = np.empty(n_pf, np.int64), np.empty(n_pf, np.uint8), np.empty(max(S, 1), np.int32)
+    rank = np.arange(max(n_contigs, 1), dtype=np.int32)
+    clen = np.zeros(max(n_contigs, 1), np.int64)
+    groups = np.zeros((2 * max(n_contigs, 1), 8), np.int64)
+    in_range = ctypes.c_int32(1)
+    ng = lib.dm_rows_emit_resident(h, p(rank), p(code), p(rdesc), p(sel), p(pos) if n_pf else None, p(flags) if n_pf else None, p(groups), len(groups),
+                                   p(clen), len(clen), ctypes.byref(in_range))
+    if ng >= 0:
+        assert (np.diff(rdesc[:, 0]) > 0).all() and rdesc[0, 0] == 0
+        assert (rdesc[:, 2] >= 0).all() and (rdesc[:, 3] >= rdesc[:, 2]).all() and (rdesc[:, 3] <= n_events).all(), (rdesc, n_events)
+        assert ((code <= 3) | (code == 255)).all() and (sel[:S] >= 0).all() and (sel[:S] < R).all()
+        # the host-statistics emit of a resident batch is refused, not misread
+        assert lib.dm_rows_emit(h, p(rank), p(np.empty((R, 7), np.float32)), p(sel), p(pos) if n_pf else None, p(flags) if n_pf else None, p(groups), len(groups),
+                                p(clen), len(clen), ctypes.byref(in_range)) < 0
+    return ng
+
+
 def fuzz_packed(lib, files, rng, iters):
     counts = {'refused': 0, 'accepted': 0}
     pk = predstore.load_packed(files[0])
@@ -136,7 +168,7 @@ def fuzz_map_read(lib, rng, iters):
 
 
 def fuzz_events_and_raw(lib, rng, iters):
-    counts = {'merge_refused': 0, 'merge_ok': 0, 'raw_refused': 0, 'raw_ok': 0}
+    counts = {'merge_refused': 0, 'merge_ok': 0, 'raw_refused': 0, 'raw_ok': 0, 'resident_refused': 0, 'resident_ok': 0}
     ref = bytes(rng.choice(list(b'ACGT'), 4000).astype(np.uint8))
     for _ in range(iters):
         n = int(rng.integers(1, 5))
@@ -215,6 +247,21 @@ def fuzz_events_and_raw(lib, rng, iters):
             counts['raw_ok'] += 1
         else:
             counts['raw_refused'] += 1
+        lib.dm_rows_destroy(h)
+        # the same records in the RESIDENT form (statistics on the device: no s_mean / s_stdv; the basecaller's values optional - without them a read
+        # that needs them is refused)
+        if fe.min() < 0:
+            fe = np.where(fe < 0, 10 ** 9, fe)
+        with_fb = bool(rng.integers(0, 2))
+        h = lib.dm_rows_create(b'C')
+        rc = lib.dm_rows_add_raw(h, nrec, p(flag), p(pos1), cig_ptr, seq_ptr, p(rlen), p(cidx), p(ev_read), p(skip), 1, ref_ptr, p(ref_len), nrec, n_ev_total,
+                                 p(mo), p(m_mean) if with_fb else None, p(m_stdv) if with_fb else None, p(m_len), p(m_base), None, None, p(fe),
+                                 int(rng.integers(0, 3)), p(rg_c), p(rg_lo), p(rg_hi))
+        if rc == 0:
+            assert drain_resident(lib, h, 1, n_ev_total) >= 0, _lib.last_error()
+            counts['resident_ok'] += 1
+        else:
+            counts['resident_refused'] += 1
         lib.dm_rows_destroy(h)
     return counts
 

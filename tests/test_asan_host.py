@@ -29,3 +29,6 @@ def test_host_abi_under_address_sanitizer(tmp_path):
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'asan', 'fuzz_host.py'), shim, scratch, '250'], env=env, capture_output=True,
                          text=True, timeout=1500)
     assert res.returncode == 0 and 'FUZZ-OK' in res.stdout, res.stdout[-1500:] + res.stderr[-4000:]
+    import re
+    m = re.search(r"'resident_ok': (\d+)", res.stdout)           # round 6: the resident form (no per-event values) went through the same damaged records
+    assert m and int(m.group(1)) > 20, res.stdout[-1500:]

@@ -437,6 +437,76 @@ def e2e_leg(precision):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+E2E_RAW_READS, E2E_RAW_REPEAT, E2E_RAW_GENOME = 4000, 20, 500000
+
+
+def _e2e_raw_gen(args):
+    from deepmod_amd import synth_reads
+    out, part, n = args
+    return synth_reads.write_synthetic_raw_run(out, n_reads=n, reads_per_file=10, genome_len=E2E_RAW_GENOME, seed=3, chrom="chrS", part=part, min_len=2000, max_len=8000)[0]
+
+
+def e2e_raw_leg(precision):
+    """The path real data takes, from RAW signal containers (int16 DAC samples + the basecaller's event tables + alignment records) to the two BED files
+    through `bin/DeepMod.py detect` with FOUR feeder processes and the command's defaults: signal normalisation and per-event statistics on the GPU (resident
+    there since round 6), CIGAR walk and window association in the feeders, feature rows assembled on the device, classifier, summary.  4,000 synthetic reads
+    are generated (untimed) and the work folder holds them 20 x by symbolic links - 80,000 reads, ~4e8 base-positions - so that the command runs for seconds,
+    not for its start-up.  Reported: the whole command, its detect step, the steady state between the first batch and the drained device."""
+    import multiprocessing, re, shutil, subprocess, tempfile
+    from deepmod_amd import synth
+    cores, _ = usable_cores()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 12e9 else None
+    tmp = tempfile.mkdtemp(prefix="dm_bench_raw_", dir=base)
+    try:
+        src = os.path.join(tmp, "src")
+        nproc = max(1, min(32, cores))
+        per = -(-E2E_RAW_READS // nproc)
+        t0 = time.perf_counter()
+        with multiprocessing.get_context("spawn").Pool(nproc) as pool:
+            files = sum(pool.map(_e2e_raw_gen, [(src, pt, per) for pt in range(nproc)]), [])
+        t_gen = time.perf_counter() - t0
+        wrk = os.path.join(tmp, "in")
+        os.makedirs(wrk)
+        os.symlink(os.path.join(src, "genome.fa"), os.path.join(wrk, "genome.fa"))
+        for k in range(E2E_RAW_REPEAT):
+            for f in files:
+                stem = f[:-len(".dmraw.npz")]
+                os.symlink(f, os.path.join(wrk, "c%02d_%s" % (k, os.path.basename(f))))
+                os.symlink(stem + ".sam", os.path.join(wrk, "c%02d_%s.sam" % (k, os.path.basename(stem))))
+        prefix = os.path.join(tmp, "model", "mod_train_synth")
+        os.makedirs(os.path.dirname(prefix))
+        synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)
+        cmd = [sys.executable, os.path.join(ROOT, "bin", "DeepMod.py"), "detect", "--wrkBase", wrk, "--Ref", os.path.join(wrk, "genome.fa"), "--modfile", prefix,
+               "--outFolder", os.path.join(tmp, "out"), "--Base", "C", "--gpus", "1", "--threads", "4", "--FileID", "raw", "--alignStr", "minimap2"]
+        t0 = time.perf_counter()
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        if res.returncode != 0:
+            return {"error": "bin/DeepMod.py detect exited %d: %s" % (res.returncode, (res.stdout[-500:] + res.stderr[-1500:]))}
+        so = res.stdout
+        m1 = re.search(r"Streaming detect: (\d+) reads, (\d+) base-positions .* in ([0-9.]+) s", so)
+        m2 = re.search(r"windows run through the classifier: (\d+) of", so)
+        m3 = re.search(r"first batch from a feeder ([0-9.]+), last batch ([0-9.]+), device drained ([0-9.]+)", so)
+        m4 = re.search(r"detect wall ([0-9.]+) s, waiting for feeders ([0-9.]+) s", so)
+        m5 = re.search(r"event statistics resident on the device for (\d+) of (\d+) rows", so)
+        m6 = re.search(r"waiting for the device ([0-9.]+) s", so)
+        reads, n_pos, t_detect = (int(m1.group(1)), int(m1.group(2)), float(m1.group(3))) if m1 else (None, None, None)
+        steady = n_pos / max(float(m3.group(3)) - float(m3.group(1)), 1e-9) if (m1 and m3) else None
+        return {"config": "synthetic raw containers (%d reads x %d by symbolic links, %d-base genome) -> bin/DeepMod.py detect --threads 4 (four feeder processes, "
+                          "streaming mode, default options: event statistics resident on the device) -> 2 BED files, 1 GPU" % (E2E_RAW_READS, E2E_RAW_REPEAT, E2E_RAW_GENOME),
+                "input_files": len(files) * E2E_RAW_REPEAT, "input_generation_s_untimed": t_gen, "wall_s": wall, "reads": reads, "base_positions": n_pos,
+                "windows_classified": int(m2.group(1)) if m2 else None, "detect_step_s": t_detect,
+                "base_positions_per_s_whole_command": n_pos / wall if n_pos else None, "base_positions_per_s_detect_step": n_pos / t_detect if n_pos else None,
+                "base_positions_per_s_steady_state": steady, "detect_wall_s": float(m4.group(1)) if m4 else None,
+                "waiting_for_feeders_s": float(m4.group(2)) if m4 else None, "waiting_for_device_s": float(m6.group(1)) if m6 else None,
+                "rows_with_statistics_resident_on_the_device": [int(m5.group(1)), int(m5.group(2))] if m5 else None,
+                "units_note": "base_positions counts every aligned base of the run (the streaming command classifies the ~quarter of them whose window is centred on the base of "
+                              "interest); steady state = base_positions / (device drained - first batch), i.e. without process start-up, model load and BED writing",
+                "stdout_tail": so.strip().splitlines()[-6:-1]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 class _FileControl:
     """Barrier / max over the ranks through the rendezvous files: the control plane of a run whose RCCL set-up failed."""
 
@@ -724,6 +794,10 @@ def main():
                     out["extras"]["e2e"] = e2e_leg(args.precision)
                 except Exception as exc:
                     out["extras"]["e2e"] = {"error": repr(exc)}
+                try:
+                    out["extras"]["e2e_raw"] = e2e_raw_leg(args.precision)
+                except Exception as exc:
+                    out["extras"]["e2e_raw"] = {"error": repr(exc)}
         tl = (out.get("extras") or {}).get("trained_like_model") or {}
         wt, mt = tl.pop("weights_obj", None), tl.pop("model_obj", None)
         if world == 1 and not args.no_cpu_baseline:

@@ -455,8 +455,7 @@ def e2e_raw_leg(precision):
     import multiprocessing, re, shutil, subprocess, tempfile
     from deepmod_amd import synth
     cores, _ = usable_cores()
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 12e9 else None
-    tmp = tempfile.mkdtemp(prefix="dm_bench_raw_", dir=base)
+    tmp = tempfile.mkdtemp(prefix="dm_bench_raw_")          # (on disk, read back through the page cache - like tools/raw_profile.py and like a real run's containers)
     try:
         src = os.path.join(tmp, "src")
         nproc = max(1, min(32, cores))

@@ -384,7 +384,15 @@ int launch_bilstm(dm_model* m, const float* d_x, long long xstride, int64_t n, f
         if (rcp) return rcp;
     }
     const long long npad = (long long)ntiles * dmk::TILE_M;
-    const int grid = std::min(2 * ntiles, m->grid_cap);          // work item = (tile, direction)
+    // work item = (tile, direction); a persistent workgroup per CU takes items round robin.  When the items do not fill the last round, the launch takes
+    // ceil(items / cap) rounds whatever the grid: it is sized to that many rounds exactly (4,198 items on 256 CUs = 17 rounds: 247 workgroups of 17 items
+    // finish when 256 workgroups of 16 or 17 would) and the CUs left over run whatever else is queued - the signal stage's kernels of the next batches -
+    // instead of idling through the last round (round 6)
+    int grid = std::min(2 * ntiles, m->grid_cap);
+    if (2 * ntiles > m->grid_cap) {
+        const int rounds = (2 * ntiles + m->grid_cap - 1) / m->grid_cap;
+        grid = (2 * ntiles + rounds - 1) / rounds;
+    }
     if (m->precision == DM_PREC_F16X3 || m->precision == DM_PREC_F16I8 || m->precision == DM_PREC_F16X3_ROLES) {
         const bool i8 = m->precision == DM_PREC_F16I8;
         const bool q16 = m->precision == DM_PREC_F16X3 && m->f16_q;

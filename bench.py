@@ -506,6 +506,27 @@ def e2e_raw_leg(precision):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+class _stdout_to_stderr:
+    """While RCCL is being set up, file descriptor 1 points at stderr: the library prints its version banner through C stdio on the first communicator of a
+    process (NCCL_DEBUG=VERSION is set on these boxes), and the contract of this script is ONE JSON line on stdout."""
+
+    def __enter__(self):
+        import ctypes
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class _FileControl:
     """Barrier / max over the ranks through the rendezvous files: the control plane of a run whose RCCL set-up failed."""
 
@@ -580,13 +601,15 @@ def main():
         try:
             if os.environ.get("DM_BENCH_BREAK_RCCL") == "1":      # test hook: the degraded mode below, without a broken RCCL
                 raise RuntimeError("DM_BENCH_BREAK_RCCL=1")
-            uid = dmcomm.rccl_unique_id() if rank == 0 else None
+            with _stdout_to_stderr():
+                uid = dmcomm.rccl_unique_id() if rank == 0 else None
         except Exception as exc:
             uid, comm_error = b"", "dm_rccl_unique_id: %r" % (exc,)
         uid = rdv.broadcast("rccl_id", uid)
         if uid:
             try:
-                communicator = dmcomm.Communicator(device, uid, rank, world)
+                with _stdout_to_stderr():
+                    communicator = dmcomm.Communicator(device, uid, rank, world)
             except Exception as exc:
                 comm_error = "dm_comm_create on rank %d: %r" % (rank, exc)
         elif comm_error is None:

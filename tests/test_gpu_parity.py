@@ -388,6 +388,9 @@ def test_bench_distributed_path_single_rank(gpu_device):
     assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
+    # round 6: ONE JSON line on stdout and nothing else - RCCL's version banner (C stdio, printed when the first communicator of a process is made) goes to stderr
+    assert [l for l in res.stdout.splitlines() if l.strip()] == [line], res.stdout[:600]
+    assert "librccl" in out["multi_gpu"]["collective_library"] and "ncclGetVersion" in out["multi_gpu"]["collective_library"]
     assert out["n_gpus"] == 1 and out["config"]["forced_dist_dry_run"] is True
     assert out["value"] > 1e6 and out["summary_check"]["touch"] > 0
     mg = out["multi_gpu"]

@@ -367,7 +367,7 @@ E2E_GENOME_LEN, E2E_COVERAGE, E2E_READS_PER_FILE, E2E_CHROM = 4_641_652, 30.0, 1
 # sha256 of the two BED files the command writes for this input with the default kernel (deterministic: integer counters, a
 # deterministic classifier - lstm16q::bilstm_f16q_kernel; the 32x32x16 kernel of rounds 2-3, DM_F16X3_SHAPE=32, gives a3c49283... / d065fd60...:
 # a different summation order moves a few near-tie windows; profiles/r04/bench_f16x3.json; round 5's merged mixed k32-step and the event-length cut of
-# DESIGN 4.1' changed both from c95a6b53... / 4775978f..., its 19-instruction cell from 595d1000... / 007c2a59..., for the same reason).  A different digest = different BED bytes.
+# profiles/HISTORY.md 4.1' changed both from c95a6b53... / 4775978f..., its 19-instruction cell from 595d1000... / 007c2a59..., for the same reason).  A different digest = different BED bytes.
 E2E_EXPECTED_BED_SHA256 = {"+": "b2b556e53d74dc62f840cb3ab9e05347139a6bea24d7a076ed5bd17271eb9d07",
                             "-": "a5a74fb041653f7e9961f76e9e6225f8e53c0579a56f0f838c66aba09e305f30"}
 

@@ -1,7 +1,7 @@
 """Generate `trained_like_tail_case.npz`: READ-SHAPED windows - events with normalised means anywhere in the +-5 clip range (a third exactly on
 the clip) and lengths of 50 .. 30,000 samples (stalled events) - evaluated by the reference's own serialized graph (tools/graphdef_interp.py on
 the .meta of rnn_conmodC_P100wd21_f7ne1u0_4) on the trained-like weights.  Why (round 5): the split-f16 kernels had a 2e-5 error on exactly such
-inputs that no synthetic-window fixture could show (DESIGN 4.1'); the oracle the GPU tests compare with is pinned here on the same kind of input.
+inputs that no synthetic-window fixture could show (profiles/HISTORY.md 4.1'); the oracle the GPU tests compare with is pinned here on the same kind of input.
 Runs ONLY in the build container (needs /root/reference); the fixture is plain data (inputs + expected outputs).
 
     python tests/golden/make_golden_tail.py

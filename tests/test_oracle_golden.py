@@ -55,7 +55,7 @@ def test_oracle_matches_interpreted_reference_graph_on_trained_like_weights():
 def test_oracle_matches_interpreted_reference_graph_on_read_shaped_windows():
     """Round 5: the pin on READ-SHAPED inputs (tests/golden/make_golden_tail.py): 192 windows of synthetic reads whose tail events carry
     normalised means on the +-5 clip and lengths up to 27,000 samples, evaluated by the reference's serialized graph on the trained-like
-    weights - the kind of input on which the split-f16 kernels had a 2e-5 error no synthetic-window fixture showed (DESIGN 4.1')."""
+    weights - the kind of input on which the split-f16 kernels had a 2e-5 error no synthetic-window fixture showed (profiles/HISTORY.md 4.1')."""
     from conftest import trained_like_weights
     w = trained_like_weights()
     g = np.load(os.path.join(GOLDEN, "trained_like_tail_case.npz"))

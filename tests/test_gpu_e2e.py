@@ -127,47 +127,16 @@ def test_detect_cli_on_raw_containers_matches_oracle_pipeline(tmp_path, gpu_devi
             open('%s/raw1/mod_pos.chrS%s.C.bed' % (out, strand), 'rb').read()
 
     genome = readmap.read_fasta(fasta)['chrS']
-    classify = lambda x: oracle_np.predict_windows_c(w, np.asarray(x, np.float32))[1]
+    from oracle_pipeline import oracle_raw_container
     by_strand = {'+': [], '-': []}
     n_reads = 0
     min_margin = 1.0
     for f in files:
-        sam = {ln.split('\t')[0]: ln.rstrip('\n').split('\t') for ln in open(f[:-len(rawreads.RAW_SUFFIX)] + '.sam') if not ln.startswith('@')}
-        for rd in rawreads.load_raw_container(f):
-            ed = rd['events_data']
-            # getEvent restated as the reference's loop (myDetect.py:237-251)
-            rows, pre_i, pre_len = [], 0, int(ed['length'][0])
-            for cur_i in range(1, len(ed)):
-                if ed['move'][cur_i] > 0:
-                    rows.append((int(ed['start'][pre_i]), pre_len, ed['model_state'][pre_i]))
-                    pre_i, pre_len = cur_i, int(ed['length'][cur_i])
-                else:
-                    pre_len += int(ed['length'][cur_i])
-            rows.append((int(ed['start'][pre_i]), pre_len, ed['model_state'][pre_i]))
-            ev = np.zeros(len(rows), dtype=rawreads.EVENT_DTYPE)
-            ev['start'] = [r[0] for r in rows]
-            ev['length'] = [r[1] for r in rows]
-            ev['model_state'] = [r[2] for r in rows]
-            sig, _ = signal_oracle.mnormalized(rd['raw'], ev)
-            mean, stdv, first_empty = signal_oracle.event_stats(sig, ev)
-            assert first_empty == len(ev)
-            s = sam[rd['read_id']]
-            o = readmap_oracle.map_read(int(s[1]), int(s[3]), s[5], s[9], genome, len(ev))
-            assert o['status'] == 'ok' and o['n_ev'] >= 50
-            refb = [r[0] for r in o['rows']]
-            readb = [r[1] for r in o['rows']]
-            ev_bases = [ms[2] for ms in ev['model_state']]
-            mf, isdif = detect_oracle.get_feature_oracle(mean, stdv, ev['length'], ev_bases, refb, readb, None, o['leftclip'],
-                                                         o['rightclip'], o['strand'], o['first_match_pos'], o['num_insertions'])
-            assert not isdif
-            n = len(ev) - o['leftclip'] - o['rightclip']
-            win = np.stack([mf[100 + i - 10:100 + i + 11, 3:] for i in range(n)]).astype(np.float32)
-            prob = oracle_np.predict_windows_c(w, win)[0]
-            min_margin = min(min_margin, float(np.abs(prob[:, 1] - 0.5).min()))
-            _, _, mod_pred = detect_oracle.mpredict1_oracle(mf, readb, ev_bases, o['leftclip'], o['rightclip'], classify)
-            by_strand[o['strand']].append({'refbase': ''.join(refb), 'readbase': ''.join(readb),
-                                           'refbasei': [int(r[2]) for r in o['rows']], 'mod_pred': mod_pred.tolist()})
-            n_reads += 1
+        got_reads, n, margin, _ties = oracle_raw_container(f, genome, w)
+        for strand in '+-':
+            by_strand[strand].extend(got_reads[strand])
+        n_reads += n
+        min_margin = min(min_margin, margin)
     assert n_reads == 18
     assert min_margin > 1e-4, 'synthetic set has a near-tie window (%.2e); pick another seed' % min_margin
     for strand, reads in by_strand.items():

@@ -498,13 +498,37 @@ def sum_handler(moptions, chr_strand_Q, device=0):
 SUBFOLDER_BATCHES = 100     # a new output sub-folder every 100 batches (myDetect.py:1161, :1168-1169)
 
 
-def discover_inputs(wrk_base, recursive):
-    """Containers under the working folder, optionally up to three levels down, sorted."""
+def discover_inputs(wrk_base, recursive, sizes=None):
+    """Containers under the working folder, optionally up to three levels down, sorted (the names `glob` would match: no hidden
+    entries, folders behind symbolic links followed).  One directory scan; `sizes` (a dict) receives path -> bytes for
+    plan_batches_sized - a folder of 10^5 containers is listed in a fraction of a second."""
+    suffixes = (predstore.CONTAINER_SUFFIX, rawreads.RAW_SUFFIX)
     found = []
-    levels = ['', '*/', '*/*/', '*/*/*/'] if recursive else ['']
-    for suffix in (predstore.CONTAINER_SUFFIX, rawreads.RAW_SUFFIX):
-        for lv in levels:
-            found.extend(glob.glob(os.path.join(wrk_base, lv + '*' + suffix)))
+
+    def scan(folder, depth):
+        try:
+            entries = list(os.scandir(folder))
+        except OSError:
+            return
+        for e in entries:
+            if e.name.startswith('.'):
+                continue
+            if e.name.endswith(suffixes):
+                path = os.path.join(folder, e.name)
+                found.append(path)
+                if sizes is not None:
+                    try:
+                        sizes[path] = e.stat().st_size
+                    except OSError:
+                        pass                            # (the feeder reports the unreadable input)
+            elif depth > 0:
+                try:
+                    if e.is_dir():
+                        scan(os.path.join(folder, e.name), depth - 1)
+                except OSError:
+                    pass
+
+    scan(wrk_base, 3 if recursive else 0)
     return sorted(found)
 
 
@@ -515,16 +539,18 @@ def plan_batches(files, per_batch):
             for i in range(0, len(files), per_batch)]
 
 
-def plan_batches_sized(files, per_batch, max_bytes):
+def plan_batches_sized(files, per_batch, max_bytes, sizes=None):
     """The work items of a streaming run: consecutive inputs, at most `per_batch` of them and at most `max_bytes` of input per batch
     (one input always fits) - a feeder hands a batch over in one shared-memory slot, and a batch that outgrows the slot takes the slow
     way through a file of its own (stream.StreamEngine.run_processes)."""
     items, cur, cur_bytes = [], [], 0
     for f in files:
-        try:
-            size = os.path.getsize(f)
-        except OSError:
-            size = 0                                    # (the feeder reports the unreadable input)
+        size = sizes.get(f) if sizes is not None else None
+        if size is None:
+            try:
+                size = os.path.getsize(f)
+            except OSError:
+                size = 0                                # (the feeder reports the unreadable input)
         if cur and (len(cur) >= per_batch or cur_bytes + size > max_bytes):
             items.append((cur, len(items) // SUBFOLDER_BATCHES, len(items)))
             cur, cur_bytes = [], 0
@@ -664,9 +690,17 @@ def _run_streaming_detect(moptions, ctx, pmanager, items, ngpu):
         return True
 
     try:
-        _run_processes(ctx, stream.stream_rank_main,
-                       [(run_opts, r, world, 0 if moptions.get('one_device') else r, work_q, result_q, feeders, feeder_procs) for r in range(world)],
-                       'streaming detect', collect)
+        if world == 1 and not int(moptions.get('rank_process', os.environ.get('DEEPMOD_RANK_PROCESS', 0))):
+            # one GPU: this process is the rank (no second interpreter to start and to import into: ~0.45 s of a 4.8 s command,
+            # profiles/r06/raw_profile.txt "GPU process running"); its feeders are processes of their own as before
+            res = stream.stream_rank_main(run_opts, 0, 1, 0, work_q, None, feeders, feeder_procs)
+            for reason, files in res['errors'].items():
+                ledger[reason].extend(files)
+            stats.append(res['stats'])
+        else:
+            _run_processes(ctx, stream.stream_rank_main,
+                           [(run_opts, r, world, 0 if moptions.get('one_device') else r, work_q, result_q, feeders, feeder_procs) for r in range(world)],
+                           'streaming detect', collect)
     finally:
         work_q.close()
     while collect():
@@ -679,7 +713,7 @@ def _run_streaming_detect(moptions, ctx, pmanager, items, ngpu):
 _BASE_OF_RUN = ['?']
 
 
-def _print_stream_stats(stats, wall, since_start=None):
+def _print_stream_stats(stats, wall, since_start=None, planning=None):
     tot = defaultdict(float)
     for st in stats:
         for k, v in st.items():
@@ -707,9 +741,9 @@ def _print_stream_stats(stats, wall, since_start=None):
         print('\tsignal stage: %d samples, %d merged events in %d requests' % (tot['signal_samples'], tot['signal_events'], tot['signal_requests']))
     if 'at_rank_start' in tot and 'at_drained' in tot:
         n, r0 = len(stats), tot['at_rank_start'] / len(stats)
-        print('\ttimeline, seconds after the command began its detect step (mean over ranks): GPU process running %.2f, feeder processes started %.2f, model on the device %.2f, '
+        print('\ttimeline, seconds after the command began its detect step (mean over ranks): %sGPU process running %.2f, feeder processes started %.2f, model on the device %.2f, '
               'first batch from a feeder %.2f, last batch %.2f, device drained %.2f, feeders gone %.2f, BED written %.2f, process done %.2f, processes joined %.2f'
-              % (r0, r0 + tot['at_feeders_started'] / n, r0 + tot['at_backend_ready'] / n, r0 + tot['at_first_batch'] / n, r0 + tot['at_last_batch'] / n, r0 + tot['at_drained'] / n,
+              % ('' if planning is None else 'inputs listed %.2f, batches planned %.2f, ' % planning, r0, r0 + tot['at_feeders_started'] / n, r0 + tot['at_backend_ready'] / n, r0 + tot['at_first_batch'] / n, r0 + tot['at_last_batch'] / n, r0 + tot['at_drained'] / n,
                  r0 + tot['at_feeders_gone'] / n, tot['at_bed_written'] / n, tot['at_rank_end'] / n, wall if since_start is None else since_start))
 
 
@@ -762,7 +796,9 @@ def mDetect_manager(moptions):
         t0 = time.time()
         cut = moptions['modfile'].rfind('/')
         moptions['modfile'] = [moptions['modfile'], './' if cut == -1 else moptions['modfile'][:cut + 1]]
-        files = discover_inputs(moptions['wrkBase'], moptions['recursive'] == 1)
+        sizes = {}
+        files = discover_inputs(moptions['wrkBase'], moptions['recursive'] == 1, sizes)
+        moptions['_t_listed'] = time.time() - moptions['_t_manager']
         print('Total files=%d' % len(files))
         out_root = moptions['outFolder'] + moptions['FileID']
         os.makedirs(out_root, exist_ok=True)
@@ -775,10 +811,11 @@ def mDetect_manager(moptions):
             # and cut them to fit the hand-over slots (feature rows are no larger than the containers they come from: a batch of
             # <= 0.8 slot of input fits its slot)
             per_batch = max(1, min(per_batch, -(-len(files) // (8 * moptions['threads']))))
-            items = plan_batches_sized(files, per_batch, int(0.8 * (int(moptions.get('feeder_slot_mb', 128)) << 20)))
+            items = plan_batches_sized(files, per_batch, int(0.8 * (int(moptions.get('feeder_slot_mb', 128)) << 20)), sizes)
             _BASE_OF_RUN[0] = moptions['Base']
+            moptions['_t_planned'] = time.time() - moptions['_t_manager']
             ledger, stats = _run_streaming_detect(moptions, ctx, pmanager, items, ngpu)
-            _print_stream_stats(stats, time.time() - t0, time.time() - moptions['_t_manager'])
+            _print_stream_stats(stats, time.time() - t0, time.time() - moptions['_t_manager'], (moptions['_t_listed'], moptions['_t_planned']))
         else:
             items = plan_batches(files, per_batch)
             ledger = _run_stored_detect(moptions, ctx, pmanager, items, ngpu)

@@ -46,3 +46,32 @@ def test_synthetic_reads_are_self_consistent(tmp_path):
             assert not rd['mfeatures'][:100 - rd['start_clip']].any()      # zero padding rows
             seen.add(rd['strand'])
     assert seen == {'+', '-'}
+
+
+def test_input_listing_equals_the_glob_patterns_of_the_manager(tmp_path):
+    """detect.discover_inputs scans each folder once; what it returns is what the reference's patterns select (`<wrkBase>/*.ext`, then one, two and
+    three folders down with --recursive 1, myDetect.py:1143-1158): no hidden entries, folders behind symbolic links followed, sorted; the sizes it
+    collects on the way give the same work items as asking the file system again."""
+    import glob
+    from deepmod_amd import detect, predstore, rawreads
+    root = str(tmp_path / 'wrk')
+    for d in ['', 'a', 'a/b', 'a/b/c', 'a/b/c/d', 'e']:
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+        for i, n in enumerate(['x' + predstore.CONTAINER_SUFFIX, '.hidden' + rawreads.RAW_SUFFIX, 'y' + rawreads.RAW_SUFFIX, 'z.txt']):
+            with open(os.path.join(root, d, n), 'w') as fh:
+                fh.write('q' * (100 * (i + 1) + len(d)))
+    os.symlink(os.path.join(root, 'a', 'b'), os.path.join(root, 'lnk'))
+    os.symlink(os.path.join(root, 'a', 'b'), os.path.join(root, '.hidden_lnk'))
+    os.symlink(os.path.join(root, 'nowhere'), os.path.join(root, 'dangling' + rawreads.RAW_SUFFIX))
+    for recursive in (False, True):
+        want = []
+        for suffix in (predstore.CONTAINER_SUFFIX, rawreads.RAW_SUFFIX):
+            for lv in (['', '*/', '*/*/', '*/*/*/'] if recursive else ['']):
+                want.extend(glob.glob(os.path.join(root, lv + '*' + suffix)))
+        sizes = {}
+        got = detect.discover_inputs(root, recursive, sizes)
+        dangling = os.path.join(root, 'dangling' + rawreads.RAW_SUFFIX)     # listed by both; the feeder reports it as an unreadable input
+        assert got == sorted(want) and dangling in got and dangling not in sizes
+        assert all(sizes[f] == os.path.getsize(f) for f in want if f != dangling)
+        assert detect.plan_batches_sized(got, 3, 450, sizes) == detect.plan_batches_sized(got, 3, 450)
+    assert detect.discover_inputs(str(tmp_path / 'nope'), True) == []

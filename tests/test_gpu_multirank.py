@@ -67,13 +67,19 @@ def test_collectives_of_the_c_abi_with_several_ranks(tmp_path, shim_env, world, 
     assert all(np.array_equal(root[name], want[k]) for k, name in enumerate(("touch", "cov", "mod")))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_command_with_several_ranks_writes_the_single_rank_bed(tmp_path, shim_env, world):
+@pytest.mark.parametrize("world,kind", [(2, 'features'), (3, 'features'), (2, 'raw')])
+def test_command_with_several_ranks_writes_the_single_rank_bed(tmp_path, shim_env, world, kind):
     """`DeepMod.py detect --gpus N` with N real GPU processes (all on device 0: DEEPMOD_ONE_DEVICE=1) and their feeders: reads sharded over
     the ranks, one reduce-scatter per contig x strand at the end, every rank formats its slice, rank 0 joins them - the BED files
-    are byte for byte those of the one-process run, which tests/test_gpu_e2e.py holds to the oracle pipeline."""
+    are byte for byte those of the one-process run, which tests/test_gpu_e2e.py holds to the oracle pipeline.  'raw': raw-signal containers
+    with their SAM records - every rank runs its own signal servers and keeps the event statistics of its feeders' batches on the device."""
     wrk = tmp_path / 'reads'
-    synth_reads.write_synthetic_run(str(wrk), n_reads=40, reads_per_file=3, genome_len=30000, seed=5, chrom='chrM2', min_len=300, max_len=1200)
+    more = []
+    if kind == 'raw':
+        synth_reads.write_synthetic_raw_run(str(wrk), n_reads=36, reads_per_file=3, genome_len=30000, seed=5, chrom='chrM2', min_len=300, max_len=1200)
+        more = ['--Ref', str(wrk / 'genome.fa'), '--alignStr', 'minimap2']
+    else:
+        synth_reads.write_synthetic_run(str(wrk), n_reads=40, reads_per_file=3, genome_len=30000, seed=5, chrom='chrM2', min_len=300, max_len=1200)
     prefix = str(tmp_path / 'model' / 'm')
     os.makedirs(os.path.dirname(prefix))
     synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)
@@ -81,12 +87,14 @@ def test_command_with_several_ranks_writes_the_single_rank_bed(tmp_path, shim_en
     for name, extra, env in (('one', [], dict(os.environ)), ('many', ['--gpus', str(world)], dict(shim_env, DEEPMOD_ONE_DEVICE='1'))):
         out = str(tmp_path / ('out_' + name))
         res = subprocess.run([sys.executable, os.path.join(ROOT, 'bin', 'DeepMod.py'), 'detect', '--wrkBase', str(wrk), '--modfile', prefix, '--outFolder', out,
-                              '--FileID', 'run', '--threads', '4', '--Base', 'C'] + extra, capture_output=True, text=True, timeout=600, env=env)
+                              '--FileID', 'run', '--threads', '4', '--Base', 'C'] + more + extra, capture_output=True, text=True, timeout=600, env=env)
         assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
         assert os.path.exists(out + '/run.done')
         beds[name] = {os.path.basename(f): open(f, 'rb').read() for f in sorted(glob.glob(out + '/run/*.bed'))}
         if name == 'many':
             assert 'ncclCommInitRank' not in res.stderr
+        if kind == 'raw':
+            assert 'event statistics resident on the device' in res.stdout, res.stdout[-1500:]
     assert len(beds['one']) == 2 and all(len(v) > 2000 for v in beds['one'].values())
     assert beds['many'] == beds['one']
 

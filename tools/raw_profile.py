@@ -1,6 +1,6 @@
 """Dev tool (GPU box): the raw-container command (`bin/DeepMod.py detect` from signal samples + event tables + alignments to BED) measured and profiled.
 
-    python tools/raw_profile.py [n_reads] [repeat] [feeders,feeders,...] [--rocprof]
+    python tools/raw_profile.py [n_reads] [repeat] [feeders,feeders,...] [--rocprof] [--servers=n,n,...]
 
   * n_reads synthetic raw reads are generated once (10 per container, the shape of tools/e2e_detect_raw.py); `repeat` > 1 multiplies the run WITHOUT
     multiplying the disk: the work folder of the measured command holds `repeat` symbolic links per container (and side-car .sam), so the run is
@@ -205,16 +205,29 @@ def main():
     synth.write_synthetic_checkpoint(prefix, seed=26, scale=4.0)
     run_detect(wrk, prefix, tmp + "/warm", feeders[0])          # page cache, library load
     last = None
+    servers = [None]
+    for a in sys.argv[1:]:
+        if a.startswith('--servers='):          # signal-stage threads of the GPU process (DEEPMOD_SIGNAL_SERVERS), one run per value and number of feeders
+            servers = [int(v) for v in a.split('=')[1].split(',')]
+    digests = set()
     for th in feeders:
-        so, wall = run_detect(wrk, prefix, "%s/out%d" % (tmp, th), th)
-        rep = parse_report(so)
-        rep.update(feeders=th, whole_command_s=round(wall, 2))
-        report["runs"].append(rep)
-        last = rep
-        for ln in rep['lines']:
-            print(ln)
-        print("%d feeders: whole command %.2f s; steady state (first batch -> device drained) %.3g base-positions/s; waiting for feeders %.0f %% of the detect wall"
-              % (th, wall, rep.get('steady_base_positions_per_s', 0), 100 * rep.get('waiting_for_feeders_s', 0) / max(rep.get('detect_wall_s', 1), 1e-9)), flush=True)
+        for sv in servers:
+            out = "%s/out%d_%s" % (tmp, th, sv)
+            so, wall = run_detect(wrk, prefix, out, th, None if sv is None else {'DEEPMOD_SIGNAL_SERVERS': str(sv)})
+            rep = parse_report(so)
+            import hashlib
+            rep.update(feeders=th, whole_command_s=round(wall, 2), signal_servers=sv,
+                       bed_sha256={os.path.basename(f): hashlib.sha256(open(f, 'rb').read()).hexdigest() for f in sorted(glob.glob(out + '/raw/*.bed'))})
+            digests.add(json.dumps(rep['bed_sha256'], sort_keys=True))
+            report["runs"].append(rep)
+            last = rep
+            for ln in rep['lines']:
+                print(ln)
+            print("%d feeders%s: whole command %.2f s; steady state (first batch -> device drained) %.3g base-positions/s; waiting for feeders %.0f %% of the detect wall"
+                  % (th, '' if sv is None else ', %d signal server thread(s)' % sv, wall, rep.get('steady_base_positions_per_s', 0),
+                     100 * rep.get('waiting_for_feeders_s', 0) / max(rep.get('detect_wall_s', 1), 1e-9)), flush=True)
+    print("BED files of the %d runs: %s" % (len(report["runs"]), "byte-identical (%s)" % ', '.join('%s %s' % (k, v[:16]) for k, v in sorted(last['bed_sha256'].items()))
+                                             if len(digests) == 1 else "DIFFERENT between runs: %d distinct digests" % len(digests)), flush=True)
     out_dir = os.path.join(ROOT, 'gpurun_out', 'r06', 'raw')
     os.makedirs(out_dir, exist_ok=True)
     if rocprof:

@@ -978,6 +978,7 @@ def signal_server(requests, answers, device: int, stats=None, results: Optional[
                 wid, path, size, n, n_raw, n_ev = req
             t0 = time.perf_counter()
             acked = False
+            blk = None
             try:
                 if norm is None:
                     norm = dmsignal.SignalNormalizer(device)
@@ -1012,10 +1013,10 @@ def signal_server(requests, answers, device: int, stats=None, results: Optional[
                         stats['signal_server_call'] += time.perf_counter() - t1
                         stats['signal_server_copy'] += t1 - t0
                     if rc != 0:
-                        blocks.give(blk)
                         results.put((wid, seq), None, 0, 'signal stage: ' + _lib.last_error())
                     else:
                         results.put((wid, seq), blk, int(flags.value), None)
+                        blk = None              # the batch loop owns it now
                 else:
                     rc = lib.dm_signal_event_stats_batch(norm._h, n, base + o['raw'], base + o['raw_off'], base + o['ev_start'], base + o['ev_length'],
                                                          base + o['ev_off'], base + o['mean'], base + o['stdv'], base + o['norm6'], base + o['first_empty'])
@@ -1033,6 +1034,9 @@ def signal_server(requests, answers, device: int, stats=None, results: Optional[
                     results.put((wid, seq), None, 0, 'signal server: %r' % (exc,))
                 else:
                     answers[wid].put('signal server: %r' % (exc,))
+            finally:
+                if blk is not None:             # a request that failed after taking its block
+                    blocks.give(blk)
             if stats is not None:
                 stats['signal_server'] += time.perf_counter() - t0
                 stats['signal_requests'] += 1

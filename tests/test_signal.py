@@ -118,8 +118,34 @@ def test_hip_device_resident_signal_and_errors():
         nz.event_stats(raw, start + np.uint64(10 ** 7), length)
     with pytest.raises(ValueError):
         nz.event_stats(raw.astype(np.float32), start, length)
+    # a first start of 2^63 and more (a damaged table) is a large index - the slice is empty, as numpy cuts it - not a negative offset into the samples
+    for huge in (2 ** 63 + 7, 2 ** 64 - 5):
+        bad = start.copy()
+        bad[0] = huge
+        with pytest.raises(_lib.DeepModHipError, match='cover no signal'):
+            nz.event_stats(raw, bad, length)
+        with pytest.raises(_lib.DeepModHipError, match='cover no signal'):
+            nz.event_stats_batch([(raw, start, length), (raw, bad, length)])
     d_raw.free()
     nz.close()
+
+
+def test_plan_of_a_batch_treats_event_starts_as_unsigned():
+    """dm_signal_plan_batch (host arithmetic, no device): the slice a read's events cover is raw[start_0 : start_last + length_last] in numpy's uint64
+    arithmetic (myDetect.py:272) - a start of 2^63 and more clamps to the end of the read (an empty slice, the read is refused), a sum that wraps is a
+    small index; inside a read such an event is an empty event and the first of them is `first_empty`."""
+    from deepmod_amd import _lib
+    lib = _lib.load()
+    raw_off, ev_off = np.array([0, 1000], np.int64), np.array([0, 4], np.int64)
+    length = np.array([10, 10, 10, 10], np.uint64)
+    fe = np.zeros(1, np.int64)
+    plan = lambda st, ln=length: lib.dm_signal_plan_batch(1, raw_off.ctypes.data, ev_off.ctypes.data, st.ctypes.data, ln.ctypes.data, fe.ctypes.data)
+    assert plan(np.array([0, 10, 20, 30], np.uint64)) == 0 and fe[0] == 4
+    for huge in (2 ** 63 + 7, 2 ** 64 - 5):
+        assert plan(np.array([huge, 10, 20, 30], np.uint64)) != 0 and 'cover no signal' in _lib.last_error()
+        assert plan(np.array([0, huge, 20, 30], np.uint64)) == 0 and fe[0] == 1            # an empty event inside the read
+    assert plan(np.array([8, 10, 20, 30], np.uint64), np.array([2, 10, 10, 2 ** 64 - 25], np.uint64)) != 0      # 30 + (2^64 - 25) wraps to 5: the end lies before the start
+    assert plan(np.array([0, 10, 20, 30], np.uint64), np.array([10, 2 ** 64 - 5, 10, 10], np.uint64)) == 0 and fe[0] == 1
 
 
 @pytest.mark.gpu

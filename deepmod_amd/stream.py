@@ -1234,6 +1234,10 @@ class HipBackend:
                 raise self._lib_mod.DeepModHipError(sig_err)
             if sig_flags & 1:
                 pb.f32 = True
+            if pb.n_rows and len(pb.rdesc) and (int(pb.rdesc[:, 2].min()) < 0 or 12 * int(pb.rdesc[:, 3].max()) > sig_block.nbytes):
+                # (the descriptors and the request come from the same feeder call; a mismatch would be a read outside the block on the device)
+                self.signal_blocks.give(sig_block)
+                raise RuntimeError('a batch whose read descriptors point outside the statistics of its signal request %r' % (pb.sig,))
         if pb.n_rows == 0:
             if sig_block is not None:
                 self.signal_blocks.give(sig_block)

@@ -600,3 +600,79 @@ def test_clips_at_the_ends_of_int64_are_a_ledger_line_not_a_wild_read(tmp_path):
         npzmap.savez_aligned(fh, **z)
     for fn in (stream._prepare_batch_c, stream._prepare_batch_py):
         assert fn(dict(mo), [bad]).errors.get("Less Event") == [bad], fn.__name__
+
+
+def test_damaged_raw_containers_cost_their_reads_and_nothing_else(tmp_path, capsys):
+    """Raw containers with damaged tables through the compiled batch builder, resident and device form: a container that cannot be read or whose offset
+    tables do not fit its columns is one line of the error ledger and the batch is the batch of the other containers; an event whose start or length is
+    absurd (2^63 and more: numpy's uint64 arithmetic, myDetect.py:272, :334-340) is an empty event or a long one exactly as in the Python restatement;
+    a read whose FIRST start is absurd covers no signal: the batched signal call refuses it and the per-read path reports it."""
+    import json
+    from deepmod_amd import npzmap
+    files, fasta = synth_reads.write_synthetic_raw_run(str(tmp_path / 'in'), n_reads=12, reads_per_file=4, genome_len=30000, seed=6,
+                                                       chrom='chrS', min_len=300, max_len=1200)
+    mo = {'Base': 'C', 'outFolder': str(tmp_path), 'fnum': 7, 'hidden': 100, 'windowsize': 21, 'Ref': fasta, 'alignStr': 'minimap2',
+          'region': [[None, None, None]], 'ConUnk': True, 'SignalGroup': 'simple', 'outLevel': 3, 'select_base': True}
+    orig = open(files[1], 'rb').read()
+    z0 = {k: np.array(v) for k, v in npzmap.load(files[1]).items()}
+    e1 = int(z0['ev_off'][1])
+
+    def build(which):
+        norm = _PostingOracleNormalizer() if which == 'resident' else _OracleNormalizer()
+        fn = stream._prepare_batch_py if which == 'py' else stream._prepare_batch_c
+        pb = fn(dict(mo), files, lambda: norm)
+        rows = stream.assemble_rows(norm.blocks[pb.sig], pb.code, pb.rdesc, pb.n_rows) if pb.sig is not None else pb.rows
+        return pb, rows
+
+    def write(**changed):
+        npzmap.savez_aligned(files[1], **dict(z0, **changed))
+
+    def edited(key, index, value):
+        a = z0[key].copy()
+        a[index] = value
+        return {key: a}
+
+    os.rename(files[1], files[1] + '.away')
+    without, rows_without = build('device')
+    os.rename(files[1] + '.away', files[1])
+    assert without.n_reads == 8
+    container_level = {
+        'truncated file': lambda: open(files[1], 'wb').write(orig[:len(orig) // 2]),
+        'not a container': lambda: open(files[1], 'wb').write(b'not a zip at all' * 100),
+        'empty file': lambda: open(files[1], 'wb').write(b''),
+        'event offsets decrease': lambda: write(**edited('ev_off', 2, e1 - 5)),
+        'event offsets past the table': lambda: write(**edited('ev_off', -1, int(z0['ev_off'][-1]) + 1000)),
+        'sample offsets past the signal': lambda: write(**edited('raw_off', -1, int(z0['raw_off'][-1]) + 10 ** 6)),
+        'sample offsets decrease': lambda: write(**edited('raw_off', 2, int(z0['raw_off'][1]) - 7)),
+        'a column shorter than the table': lambda: write(ev_move=z0['ev_move'][:-100]),
+        'fewer reads in the meta record than in the tables': lambda: write(meta=np.array(json.dumps(json.loads(str(z0['meta']))[:-1]))),
+    }
+    for name, damage in container_level.items():
+        damage()
+        for which in ('resident', 'device'):
+            pb, rows = build(which)
+            assert dict(pb.errors) == {'Cannot open fast5 or other errors': [files[1]]}, (name, which, dict(pb.errors))
+            assert pb.n_reads == 8 and pb.groups == without.groups and np.array_equal(pb.pos, without.pos) and np.array_equal(rows, rows_without), (name, which)
+            assert (pb.sig is not None) == (which == 'resident')
+    event_level = {
+        'an event in the middle starts at 2^64 - 3': edited('ev_start', e1 + 50, 2 ** 64 - 3),
+        'an event 2^63 samples long': edited('ev_length', e1 + 50, 2 ** 63),
+        'a first start of 2^63 + 11': edited('ev_start', e1, 2 ** 63 + 11),
+    }
+    for name, change in event_level.items():
+        write(**change)
+        ref, rows_ref = build('py')                                         # classic form: every row has its position and flags
+        classic = stream._prepare_batch_c(dict(mo, select_base=False), files, lambda: _OracleNormalizer())
+        assert classic.n_reads == ref.n_reads == 12 and classic.groups == ref.groups and np.array_equal(classic.pos, ref.pos) and np.array_equal(classic.flags, ref.flags)
+        assert np.array_equal(classic.rows, rows_ref, equal_nan=True), name
+        want = np.flatnonzero((ref.flags[:ref.n_rows] & 1) != 0)
+        for which in ('resident', 'device'):
+            pb, rows = build(which)
+            assert pb.n_reads == 12 and np.array_equal(rows, rows_ref, equal_nan=True), (name, which)
+            if which == 'resident' and 'first' in name:
+                # dm_signal_plan_batch refuses the batch ("events cover no signal") and it is built read by read, in the classic form
+                assert pb.sig is None and pb.sel is None and np.array_equal(pb.pos, ref.pos) and np.array_equal(pb.flags, ref.flags)
+                continue
+            assert (pb.sig is not None) == (which == 'resident') and np.array_equal(pb.sel, want), (name, which)
+            assert np.array_equal(pb.pos[:len(want)], ref.pos[want]) and np.array_equal(pb.pos[len(want):], ref.pos[ref.n_rows:]), (name, which)
+    capsys.readouterr()

@@ -68,6 +68,42 @@ def test_oracle_matches_interpreted_reference_graph_on_read_shaped_windows():
     assert np.abs(prob_n - g["prob"]).max() <= 1e-6
 
 
+def test_tensorflow_cpu_activation_kernels_move_no_probability_by_1e_5():
+    """The part of the reference's arithmetic no fixture pins is inside TensorFlow's kernels.  Its largest piece, restated from the published
+    algorithm: on CPU TensorFlow 1.x computes tanh and sigmoid with Eigen's float32 rational approximations (`generic_fast_tanh_float`,
+    `scalar_logistic_op<float>`; oracle_np.eigen_fast_tanh / eigen_logistic), not libm.  They are within 4e-7 of libm, and the whole graph evaluated
+    with them stays within 5e-6 of the interpreted reference graph on every fixture (classes equal) and within 1e-5 of the libm oracle on 4,000 windows
+    at weight scale 4 - a twentieth of the path's tolerance (1e-4)."""
+    from conftest import trained_like_weights
+    x = np.linspace(-20.0, 20.0, 400001).astype(np.float32)
+    assert np.abs(oracle_np.eigen_fast_tanh(x) - np.tanh(x.astype(np.float64))).max() < 4e-7
+    assert np.abs(oracle_np.eigen_logistic(x) - 1.0 / (1.0 + np.exp(-x.astype(np.float64)))).max() < 4e-7
+    assert oracle_np.eigen_fast_tanh(np.float32([-50, 50, 0])).tolist() == [-1.0, 1.0, 0.0]
+    worst = 0.0
+    for path in FIXTURES:
+        g = np.load(path)
+        w = synth.synthetic_weights(int(g["seed_w"]), float(g["scale"]))
+        prob, cls, _ = oracle_np.predict_windows_np(w, g["X"], activations='eigen')
+        worst = max(worst, float(np.abs(prob - g["prob"]).max()))
+        assert np.array_equal(cls, g["cls"])
+    w = trained_like_weights()
+    for name in ("trained_like_case.npz", "trained_like_tail_case.npz"):
+        g = np.load(os.path.join(GOLDEN, name))
+        prob, cls, _ = oracle_np.predict_windows_np(w, g["X"], activations='eigen')
+        worst = max(worst, float(np.abs(prob - g["prob"]).max()))
+        assert np.array_equal(cls, g["cls"])
+    assert worst <= 5e-6, worst
+    w = synth.synthetic_weights(26, 4.0)
+    xw = synth.synthetic_windows(4000, seed=5)
+    pe, ce, _ = oracle_np.predict_windows_np(w, xw, activations='eigen')
+    pl, cl, _ = oracle_np.predict_windows_np(w, xw)
+    assert np.abs(pe - pl).max() <= 1e-5
+    flips = ce != cl
+    assert (np.abs(pl[flips, 1] - 0.5) <= 1e-5).all()
+    with pytest.raises(ValueError):
+        oracle_np.predict_windows_np(w, xw[:2], dtype=np.float64, activations='eigen')
+
+
 def test_torch_restatement_equals_c_oracle():
     """oracle/oracle_torch.py (bench.py's cpu_baseline.gemm leg) is the same graph as the C oracle."""
     from oracle import oracle_torch

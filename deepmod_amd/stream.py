@@ -1339,6 +1339,9 @@ class HipBackend:
                 self.signal_blocks.give(st['sig_block'])
             st['host'] = st['dev'] = st['sig_block'] = None
         if self.signal_blocks is not None:
+            if self.signal_results is not None:         # statistics whose batch never arrived (a feeder that failed after posting its request)
+                for key in self.signal_results.pending():
+                    self.signal_blocks.give(self.signal_results.take(key, timeout=1.0)[0])
             self.signal_blocks.close()
         self.sess.close()
 

@@ -180,3 +180,29 @@ def test_rows_assembled_on_the_device_equal_the_host_rows(tmp_path, gpu_device):
         backend.close()
     assert beds['device'] == beds['host'] and len(beds['device']) == 2 and all(len(v) > 1000 for v in beds['device'].values())
     norm.close()
+
+
+@pytest.mark.gpu
+def test_device_block_pool_reuses_the_smallest_block_that_fits(gpu_device):
+    """stream.DeviceBlockPool: the pooled device blocks of resident signal requests - a block is allocated only when no free one is large enough, the smallest
+    free block that fits is the one handed out, blocks given back are used again, close() frees what is free."""
+    pool = stream.DeviceBlockPool(gpu_device)
+    a = pool.take(1 << 20)
+    b = pool.take(8 << 20)
+    assert pool.allocated == 2 and a.nbytes >= (1 << 20) and b.nbytes >= (8 << 20) and a.ptr != b.ptr
+    pool.give(b)
+    pool.give(a)
+    pool.give(None)
+    c = pool.take(1 << 19)                 # the 1 MB block, not the 8 MB one
+    assert c.ptr == a.ptr and pool.allocated == 2
+    d = pool.take(4 << 20)
+    assert d.ptr == b.ptr and pool.allocated == 2
+    e = pool.take(4 << 20)                 # nothing free: a new one
+    assert pool.allocated == 3 and e.ptr not in (a.ptr, b.ptr)
+    x = np.arange(1024, dtype=np.float32)
+    e.view_upload(x) if hasattr(e, 'view_upload') else None
+    for blk in (c, d, e):
+        pool.give(blk)
+    pool.close()
+    assert pool.take(16).nbytes >= 16 and pool.allocated == 4
+    pool.close()

@@ -7,6 +7,8 @@ import multiprocessing
 import os
 import queue
 
+import pytest
+
 import numpy as np
 
 from deepmod_amd import stream, synth, synth_reads
@@ -676,3 +678,23 @@ def test_damaged_raw_containers_cost_their_reads_and_nothing_else(tmp_path, caps
             assert (pb.sig is not None) == (which == 'resident') and np.array_equal(pb.sel, want), (name, which)
             assert np.array_equal(pb.pos[:len(want)], ref.pos[want]) and np.array_equal(pb.pos[len(want):], ref.pos[ref.n_rows:]), (name, which)
     capsys.readouterr()
+
+
+def test_signal_results_registry():
+    """stream.SignalResults: what the signal server threads of a GPU process hand to its batch loop - a result is taken once, by the (feeder, number) of its
+    request, in any order; a taker waits for a result that is still being computed and gives up (loudly) on one that never comes."""
+    import threading
+    import time
+    reg = stream.SignalResults()
+    reg.put((0, 2), 'block-b', 1)
+    reg.put([1, 1], 'block-c', 0, None)
+    assert sorted(reg.pending()) == [(0, 2), (1, 1)]
+    assert reg.take((1, 1)) == ('block-c', 0, None) and reg.take([0, 2]) == ('block-b', 1, None) and reg.pending() == []
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match='never answered'):
+        reg.take((0, 2), timeout=0.2)                         # taken once
+    assert 0.15 < time.perf_counter() - t0 < 2.0
+    late = threading.Timer(0.2, lambda: reg.put((3, 7), None, 0, 'signal stage: no device'))
+    late.start()
+    assert reg.take((3, 7), timeout=5.0) == (None, 0, 'signal stage: no device')
+    late.join()

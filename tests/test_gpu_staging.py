@@ -199,10 +199,10 @@ def test_device_block_pool_reuses_the_smallest_block_that_fits(gpu_device):
     assert d.ptr == b.ptr and pool.allocated == 2
     e = pool.take(4 << 20)                 # nothing free: a new one
     assert pool.allocated == 3 and e.ptr not in (a.ptr, b.ptr)
-    x = np.arange(1024, dtype=np.float32)
-    e.view_upload(x) if hasattr(e, 'view_upload') else None
     for blk in (c, d, e):
         pool.give(blk)
     pool.close()
-    assert pool.take(16).nbytes >= 16 and pool.allocated == 4
+    f = pool.take(16)                      # a closed pool starts over
+    assert f.nbytes >= 16 and pool.allocated == 4
+    pool.give(f)
     pool.close()

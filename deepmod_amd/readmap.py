@@ -8,7 +8,6 @@ plain FASTA reader (no external binaries in this image) and the HDF5 prediction 
 from __future__ import annotations
 
 import ctypes
-import os
 from collections import defaultdict
 from typing import Dict
 

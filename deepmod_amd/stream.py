@@ -27,7 +27,7 @@ import os
 import queue
 import threading
 import time
-from collections import defaultdict, deque
+from collections import defaultdict
 from typing import Dict, Iterable, List, Optional, Tuple
 
 import numpy as np

@@ -7,7 +7,6 @@
     sum_handler restatements) byte for byte, away from near-tie windows (|p1 - 0.5| < 1e-4), which are enumerated;
   * the end-to-end rate and the host stages' share are printed (pytest -s) and written to gpurun_out/.
 """
-import glob
 import json
 import multiprocessing
 import os

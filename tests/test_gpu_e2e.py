@@ -88,8 +88,7 @@ def test_detect_cli_on_raw_containers_matches_oracle_pipeline(tmp_path, gpu_devi
     """The whole path from DAC samples: GPU signal normalisation + event statistics, SAM records through
     dm_map_read, features, BiLSTM, summary — against the oracle chain (numpy signal oracle, Python alignment-walk
     restatement, loop-level get_Feature / mPredict1 / sum_handler restatements, C classifier)."""
-    from deepmod_amd import rawreads, readmap
-    from oracle import readmap_oracle, signal_oracle
+    from deepmod_amd import readmap
     wrk = tmp_path / 'raw'
     files, fasta = synth_reads.write_synthetic_raw_run(str(wrk), n_reads=18, reads_per_file=4, genome_len=20000, seed=5,
                                                        chrom='chrS')

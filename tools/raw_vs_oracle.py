@@ -31,7 +31,6 @@ def _gen(args):
 
 
 def _oracle(args):
-    import numpy as np
     from deepmod_amd import readmap, synth
     from oracle_pipeline import oracle_raw_container
     path, fasta = args

@@ -115,21 +115,46 @@ def _central_directory(mm):
     return out
 
 
-def load(path: str) -> Dict[str, np.ndarray]:
-    """name -> array for every member of an .npz file; views into one read-only mapping where the member is stored."""
+_MADV_POPULATE_READ = 22           # Linux 5.14+: map (and read in) the pages of a range now, like MAP_POPULATE for a whole mapping
+_populate_ranges_ok = [hasattr(mmap.mmap, 'madvise')]
+
+
+def _populate(mm, ranges) -> bool:
+    """Map the pages of the byte ranges [(first, end)] of `mm` now.  False: this kernel cannot (the caller maps the whole file instead)."""
+    page = mmap.PAGESIZE
+    merged = []
+    for lo, hi in sorted((lo // page * page, -(-hi // page) * page) for lo, hi in ranges if hi > lo):
+        if merged and lo <= merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], hi)
+        else:
+            merged.append([lo, hi])
+    try:
+        for lo, hi in merged:
+            mm.madvise(_MADV_POPULATE_READ, lo, min(hi, len(mm)) - lo)
+    except (OSError, ValueError):
+        return False
+    return True
+
+
+def load(path: str, lazy=()) -> Dict[str, np.ndarray]:
+    """name -> array for every member of an .npz file; views into one read-only mapping where the member is stored.
+    lazy: members the caller will probably not read (a raw container's basecaller mean / stdv columns: a quarter of its bytes, needed only for a read with
+    an empty event) - their pages are neither mapped nor read from the disk until somebody touches them."""
     out: Dict[str, np.ndarray] = {}
     fallback = []
+    want_ranges = bool(lazy) and _populate_ranges_ok[0]
     with open(path, 'rb') as fh:
         try:
             # every member is read by whoever loads a container: map the pages in one go instead of one fault per 4 KB (a third of dm_events_merge's
             # time on a 60-byte-per-event table that comes out of the page cache)
-            mm = mmap.mmap(fh.fileno(), 0, flags=mmap.MAP_SHARED | getattr(mmap, 'MAP_POPULATE', 0), prot=mmap.PROT_READ)
+            mm = mmap.mmap(fh.fileno(), 0, flags=mmap.MAP_SHARED | (0 if want_ranges else getattr(mmap, 'MAP_POPULATE', 0)), prot=mmap.PROT_READ)
         except (ValueError, OSError):
             mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
         infos = _central_directory(mm)
         if infos is None:
             with zipfile.ZipFile(fh) as zf:
                 infos = [(i.filename, i.compress_type, i.header_offset) for i in zf.infolist()]
+    ranges = []
     for filename, method, ho in infos:
         name = filename[:-4] if filename.endswith('.npy') else filename
         if method != zipfile.ZIP_STORED:
@@ -154,6 +179,8 @@ def load(path: str) -> Dict[str, np.ndarray]:
             fallback.append(name)
             continue
         count = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
+        if want_ranges and name not in lazy:
+            ranges.append((cur.pos, cur.pos + count * dtype.itemsize))
         if cur.pos % max(dtype.alignment, 1):
             # a member starts wherever the zip local header ends: a view at an offset that is not a multiple of the item alignment
             # would hand misaligned int64 / float64 pointers to the C ABI - such a member is copied
@@ -161,6 +188,8 @@ def load(path: str) -> Dict[str, np.ndarray]:
         else:
             arr = np.frombuffer(mm, dtype, count, cur.pos)
         out[name] = arr.reshape(shape, order='F' if fortran else 'C')
+    if want_ranges and not _populate(mm, ranges):
+        _populate_ranges_ok[0] = False                  # (an older kernel: from now on whole files are mapped at once, as before)
     if fallback:
         z = np.load(path, allow_pickle=False)
         for name in fallback:

@@ -291,7 +291,7 @@ def _prepare_batch_c(moptions, files: List[str], make_normalizer=None, alloc=Non
             opened = []
             for f5f in raw_files:
                 try:
-                    z = npzmap.load(f5f)
+                    z = npzmap.load(f5f, lazy=('ev_mean', 'ev_stdv'))
                     if 'format' not in z:
                         raise ValueError('format-1 raw container')
                     meta = json.loads(str(z['meta']))

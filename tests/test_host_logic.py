@@ -216,6 +216,19 @@ def test_npzmap_views_equal_numpy_load(tmp_path):
         assert not aligned[k].flags.writeable and aligned[k].ctypes.data % 64 == 0, k
     z = np.load(str(tmp_path / 'aligned.npz'))
     assert all(np.array_equal(z[k], v) for k, v in arrays.items())
+    # lazy members: the same views, their pages left to the first touch; a kernel without MADV_POPULATE_READ maps whole files as before
+    for name in ('aligned.npz', 'stored.npz', 'deflated.npz'):
+        lazy = npzmap.load(str(tmp_path / name), lazy=('f32', 'fortran', 'not a member'))
+        assert sorted(lazy) == sorted(arrays) and all(np.array_equal(lazy[k], v) for k, v in arrays.items())
+    import mmap
+    assert npzmap._populate(mmap.mmap(-1, 1 << 16), [(100, 5000), (4000, 9000), (70000, 60000), (60000, 1 << 16)]) in (True, False)    # overlapping, empty, up to the end
+    ok = npzmap._populate_ranges_ok[0]
+    try:
+        npzmap._populate_ranges_ok[0] = False
+        whole = npzmap.load(str(tmp_path / 'aligned.npz'), lazy=('f32',))
+        assert all(np.array_equal(whole[k], v) for k, v in arrays.items())
+    finally:
+        npzmap._populate_ranges_ok[0] = ok
 
 
 def test_stored_chunks_equal_the_per_read_tables(tmp_path):

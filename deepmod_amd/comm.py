@@ -102,7 +102,28 @@ class Communicator:
         self._lib = _lib.load()
         self.device, self.rank, self.nranks = device, rank, nranks
         buf = ctypes.create_string_buffer(unique_id, 128)
-        self._h = self._lib.dm_comm_create(device, buf, rank, nranks)
+        # ncclCommInitRank blocks until every rank has joined.  A peer that died before it got here, or a collective library that cannot reach it,
+        # would leave this process waiting for ever inside the library: a watchdog ends it (exit code 3, the reason on stderr - the manager then
+        # stops the other ranks) after DEEPMOD_COMM_TIMEOUT seconds (default 600; 0 = wait for ever)
+        import os
+        import sys
+        import threading
+        timeout = float(os.environ.get('DEEPMOD_COMM_TIMEOUT', '600') or 0)
+        watchdog = None
+        if timeout > 0:
+            def give_up():
+                sys.stderr.write("dm_comm_create (ncclCommInitRank, rank %d of %d on device %d) has not returned after %.0f s: a rank that never joined, or a "
+                                 "collective library that cannot reach its peers; giving up (DEEPMOD_COMM_TIMEOUT)\n" % (rank, nranks, device, timeout))
+                sys.stderr.flush()
+                os._exit(3)
+            watchdog = threading.Timer(timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            self._h = self._lib.dm_comm_create(device, buf, rank, nranks)
+        finally:
+            if watchdog is not None:
+                watchdog.cancel()
         if not self._h:
             raise _lib.DeepModHipError("dm_comm_create: " + _lib.last_error())
 

@@ -212,11 +212,12 @@ def test_two_rank_run_that_cannot_build_its_communicator_fails_fast_and_clean(tm
     t0 = time.time()
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'bin', 'DeepMod.py'), 'detect', '--wrkBase', str(wrk), '--modfile', prefix, '--outFolder', out,
                           '--FileID', 'two', '--threads', '4', '--Base', 'C', '--gpus', '2'], capture_output=True, text=True, timeout=300,
-                         env=dict(os.environ, DEEPMOD_ONE_DEVICE='1'))
+                         env=dict(os.environ, DEEPMOD_ONE_DEVICE='1', DEEPMOD_COMM_TIMEOUT='60'))
     took = time.time() - t0
-    # (how long RCCL takes to refuse is RCCL's bootstrap on this box - seconds as a rule, once over two minutes; what is asserted is that the command ends by itself)
-    assert res.returncode != 0 and took < 280, (res.returncode, took, res.stderr[-2000:])
-    assert 'ncclCommInitRank' in res.stderr and 'a streaming detect worker died' in res.stderr, (took, res.stderr[-3000:])
+    # RCCL refuses within seconds as a rule; on a box where its bootstrap never comes back (seen once: > 2 min) the communicator watchdog ends the rank
+    # (comm.Communicator, DEEPMOD_COMM_TIMEOUT) - either way the command ends by itself, with the reason on stderr
+    assert res.returncode != 0 and took < 150, (res.returncode, took, res.stderr[-2000:])
+    assert ('ncclCommInitRank' in res.stderr or 'has not returned after 60 s' in res.stderr) and 'a streaming detect worker died' in res.stderr, (took, res.stderr[-3000:])
     assert not os.path.exists(out + '/two.done') and not glob.glob(out + '/two/*.bed')
     if os.path.isdir('/dev/shm'):
         assert not [f for f in set(os.listdir('/dev/shm')) - before if f.startswith('deepmod')]

@@ -118,3 +118,17 @@ def test_bench_eight_ranks_merge_through_the_collective_calls(shim_env):
     assert [r["rank"] for r in mg["per_rank"]] == list(range(world))
     assert out["summary_check"]["touch"] == sum(r["slice_sums"][0] for r in mg["per_rank"]) > 0
     assert mg["measured_on_hardware_with_more_than_one_rank"] is False and "libshmccl.so (ncclGetVersion" in mg["collective_library"]
+
+
+def test_a_rank_whose_peer_never_joins_gives_up(tmp_path, shim_env):
+    """comm.Communicator's watchdog: ncclCommInitRank blocks until every rank has joined; a process whose peer never arrives ends by itself after
+    DEEPMOD_COMM_TIMEOUT seconds - exit code 3, the reason on stderr - instead of waiting inside the collective library (the stand-in waits 60 s)."""
+    import time
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from deepmod_amd import comm\n"
+            "comm.Communicator(0, comm.rccl_unique_id(), 0, 2)\n"
+            "print('created')\n" % ROOT)
+    t0 = time.time()
+    res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120, env=dict(shim_env, DEEPMOD_COMM_TIMEOUT='3'))
+    assert res.returncode == 3 and time.time() - t0 < 40, (res.returncode, res.stderr[-1500:])
+    assert 'has not returned after 3 s' in res.stderr and 'created' not in res.stdout

@@ -130,5 +130,5 @@ def test_a_rank_whose_peer_never_joins_gives_up(tmp_path, shim_env):
             "print('created')\n" % ROOT)
     t0 = time.time()
     res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120, env=dict(shim_env, DEEPMOD_COMM_TIMEOUT='3'))
-    assert res.returncode == 3 and time.time() - t0 < 40, (res.returncode, res.stderr[-1500:])
+    assert res.returncode == 3 and time.time() - t0 < 100, (res.returncode, res.stderr[-1500:])
     assert 'has not returned after 3 s' in res.stderr and 'created' not in res.stdout
